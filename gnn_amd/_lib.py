@@ -1,0 +1,70 @@
+"""ctypes binding of libmgn_hip.so (the C ABI declared in include/mgn_hip.h).
+
+There is no fallback: if the shared library is missing or a call fails, a
+RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgn_hip.so")
+ABI_VERSION = 1
+H = 128
+MAX_FEAT = 16
+MAX_DEC_OUT = 32
+
+
+class MgnMlp(C.Structure):
+    _fields_ = [("w0", C.c_void_p), ("b0", C.c_void_p), ("w1", C.c_void_p), ("b1", C.c_void_p),
+                ("ln_w", C.c_void_p), ("ln_b", C.c_void_p)]
+
+
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_MLP = C.POINTER(MgnMlp)
+
+# name -> (restype, argtypes); must list every symbol include/mgn_hip.h declares
+SIGNATURES = {
+    "mgn_abi_version": (C.c_int, []),
+    "mgn_last_error": (C.c_char_p, []),
+    "mgn_cells_to_edge_index": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _P]),
+    "mgn_receiver_csr": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "mgn_mp_project": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P]),
+    "mgn_mp_edge": (C.c_int, [_P, _P, _P, _P, _P, _P, _MLP, _P, _P, _I64, _I64, _P]),
+    "mgn_mp_node": (C.c_int, [_P, _P, _P, _MLP, _P, _I64, _P]),
+    "mgn_node_features": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),
+    "mgn_edge_features": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgn_feature_sums_scratch_bytes": (_I64, [_I64, _I32]),
+    "mgn_feature_sums": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
+    "mgn_norm_update": (C.c_int, [_P, _P, _P, _I32, _I64, _F, _P, _P]),
+    "mgn_normalize": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),
+    "mgn_encode": (C.c_int, [_P, _I32, _P, _MLP, _P, _I64, _P]),
+    "mgn_decode": (C.c_int, [_P, _MLP, _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgn_gather_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
+    "mgn_scatter_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python gnn_amd/csrc/build.py` "
+                "(hipcc, --offload-arch=gfx950). There is no CPU or PyTorch fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        if l.mgn_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libmgn_hip.so ABI {l.mgn_abi_version()} != binding {ABI_VERSION}")
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().mgn_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

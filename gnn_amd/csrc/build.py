@@ -1,0 +1,45 @@
+"""Builds libmgn_hip.so (gfx950) in-tree with hipcc.  Used by ``__graft_entry__.build()``
+and runnable by hand: ``python gnn_amd/csrc/build.py``."""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+SOURCES = ["mgn_kernels.hip", "mgn_host.cpp"]
+OUT = os.path.join(PKG, "libmgn_hip.so")
+
+
+def hipcc_path() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found; set HIPCC")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    newest = max(os.path.getmtime(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith((".hip", ".cpp", ".h")))
+    newest = max(newest, os.path.getmtime(os.path.join(PKG, "..", "include", "mgn_hip.h")))
+    return newest > os.path.getmtime(OUT)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return OUT
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+    res = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    if verbose:
+        print(res.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -1,0 +1,783 @@
+// Device side of libmgn_hip.so: MeshGraphNets processor, encoder, decoder and normaliser
+// kernels for gfx950 (MI355X), fp32 throughout.
+//
+// Common structure of the MLP kernels ("row-tile" kernels)
+//   * a workgroup is 4 waves (256 threads) and walks a contiguous range of 32-row tiles;
+//   * wave w owns output features [32w, 32w+32) of every 128-wide Linear and keeps its
+//     slice of the weights in registers for the whole kernel (loaded once);
+//   * the activation tile lives in LDS as rows of K floats padded by one 16-byte chunk,
+//     so that the 16 lanes of a ds_read_b128 group (16 different rows, same chunk) hit
+//     16 different bank groups while every chunk stays at a constant offset from the
+//     row base (immediate-offset addressing, no per-chunk address registers);
+//   * products run on v_mfma_f32_32x32x2_f32 with A = weights (row = feature) and
+//     B = activations (column = tile row): lane (j = lane & 31, h = lane >> 5) ends up
+//     holding, for tile row j, features 32w + 8g + 4h + {0..3} in accumulator
+//     registers 4g .. 4g+3 -- i.e. whole 16-byte chunks of that row;
+//   * the k index consumed by MFMA step t of chunk c is 8c + 4h + t for both operands,
+//     so each lane fetches its operands with one 16-byte access per four MFMAs.
+//
+// Sums over edges use no atomics: edges are in receiver-major order, a workgroup owns
+// whole receivers, and one thread per feature column adds the rows of a segment in
+// order, so results do not depend on the launch geometry.
+#include <hip/hip_runtime.h>
+
+#include "mgn_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int H = MGN_H;    // latent width
+constexpr int TM = 32;      // rows per tile
+constexpr int NT = 256;     // threads per workgroup
+constexpr float LN_EPS = 1e-5f;
+
+// float offset of 16-byte chunk q of row `row` in a tile whose rows hold k4 chunks (+1 pad)
+__device__ __forceinline__ constexpr int tile_floats(int k4) { return TM * (4 * k4 + 4); }
+__device__ __forceinline__ int toff(int row, int q, int k4) { return row * (4 * k4 + 4) + 4 * q; }
+
+// Register-resident weight slice: for output feature `feat`, the k values this lane
+// feeds to the MFMAs of chunk c are W[feat][koff + 8c + 4h + 0..3].
+template <int KC>
+__device__ __forceinline__ void load_wfrag(f32x4 (&w)[KC], const float* __restrict__ W, int ldw, int koff,
+                                           int feat, int h, bool valid = true) {
+    const float* p = W + (size_t)feat * ldw + koff + 4 * h;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) w[c] = valid ? *(const f32x4*)(p + 8 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// acc[feature][row] += W[feature][k] * tile[row][k] over k = 8*KC values starting at chunk qoff
+template <int KC>
+__device__ __forceinline__ f32x16 wave_gemm(const float* tile, int k4, int qoff, const f32x4 (&w)[KC],
+                                            int j, int h, f32x16 acc) {
+#pragma unroll
+    for (int c = 0; c < KC; ++c) {
+        const f32x4 a = *(const f32x4*)(tile + toff(j, qoff + 2 * c + h, k4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0], a[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1], a[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][2], a[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][3], a[3], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ f32x16 acc_from_vec(const float* vec_lds, int w, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *(const f32x4*)(vec_lds + 32 * w + 8 * g + 4 * h);
+        acc[4 * g + 0] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+    }
+    return acc;
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    return v;
+}
+
+// LayerNorm over the 128 features of every tile row (two-pass: mean, then centred
+// variance, biased, eps inside the root).  `red` is LDS float[2][4][TM].  Contains two
+// workgroup barriers; after the first one every wave has finished reading whatever
+// tile fed the accumulators.
+__device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, int j, int h,
+                                                 const float* gamma_lds, const float* beta_lds) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    s += __shfl_xor(s, 32);
+    if (h == 0) red[w * TM + j] = s;
+    __syncthreads();
+    const float mean = (red[j] + red[TM + j] + red[2 * TM + j] + red[3 * TM + j]) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    q += __shfl_xor(q, 32);
+    if (h == 0) red[4 * TM + w * TM + j] = q;
+    __syncthreads();
+    const float var = (red[4 * TM + j] + red[5 * TM + j] + red[6 * TM + j] + red[7 * TM + j]) * (1.0f / H);
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ga = *(const f32x4*)(gamma_lds + 32 * w + 8 * g + 4 * h);
+        const f32x4 be = *(const f32x4*)(beta_lds + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[4 * g + t] = v[4 * g + t] * rstd * ga[t] + be[t];
+    }
+    return v;
+}
+
+// store the accumulator (row j, features 32w..32w+31) into a [TM][H] LDS tile
+__device__ __forceinline__ void acc_to_tile(float* tile, f32x16 v, int w, int j, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *(f32x4*)(tile + toff(j, 8 * w + 2 * g + h, H / 4)) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+}
+
+// Blocks b and b + 8 share an XCD (and its L2); hand each XCD a contiguous run of ranges.
+__device__ __forceinline__ int range_of_block(int b, int nb) {
+    return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, long long target) {
+    int lo = 0, hi = n;                       // first index with a[i] >= target, in [0, n]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)a[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ======================================================================== processor: edges
+struct EdgeArgs {
+    const float* e_in; const float* ps; const float* pr;
+    const int* rowptr; const int* sender; const int* recv;
+    const float* w0; const float* w1; const float* b1; const float* ln_w; const float* ln_b;
+    float* e_out; float* aggr;
+    int n_edges; int n_nodes;
+};
+
+__global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) float X[2][tile_floats(H / 4)];   // staged e_in tile, double buffered
+    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];     // hidden tile, then the edge output
+    __shared__ __attribute__((aligned(16))) float vec[3][H];      // b1, ln_w, ln_b
+    __shared__ float red[8 * TM];
+    __shared__ int rid[2][TM + 1];
+    __shared__ int srange[2];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+
+    f32x4 wa[16], wb[16];
+    load_wfrag<16>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
+    load_wfrag<16>(wb, a.w1, H, 0, 32 * w + j, h);
+    if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; }
+    if (t == 0) {
+        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+        const long long lo = (long long)rho * a.n_edges / nb, hi = (long long)(rho + 1) * a.n_edges / nb;
+        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
+        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
+    }
+    __syncthreads();
+    const int e0 = srange[0], e1 = srange[1];
+    if (e0 >= e1) return;
+
+    const int srow = t >> 5, sq = t & 31;       // staging map: rows srow + 8*it, chunk sq
+    f32x4 pre[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int r = min(e0 + srow + 8 * it, e1 - 1);
+        pre[it] = *(const f32x4*)(a.e_in + (size_t)r * H + 4 * sq);
+    }
+    float run = 0.f;                            // running segment sum (threads 0..127: one column each)
+    int buf = 0;
+    for (int base = e0; base < e1; base += TM, buf ^= 1) {
+        const int nvalid = min(TM, e1 - base);
+        float* Xb = X[buf];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) *(f32x4*)(Xb + toff(srow + 8 * it, sq, H / 4)) = pre[it];
+        if (t <= TM) rid[buf][t] = (base + t < e1) ? a.recv[base + t] : -1;
+        __syncthreads();                                                     // (A)
+        if (base + TM < e1) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = min(base + TM + srow + 8 * it, e1 - 1);
+                pre[it] = *(const f32x4*)(a.e_in + (size_t)r * H + 4 * sq);
+            }
+        }
+        // per-node projections of this lane's edge: sender part and receiver part (+ bias)
+        const int ej = min(base + j, e1 - 1);
+        const int s = a.sender[ej], r = a.recv[ej];
+        f32x4 gs[4], gr[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            gs[g] = *(const f32x4*)(a.ps + (size_t)s * H + 32 * w + 8 * g + 4 * h);
+            gr[g] = *(const f32x4*)(a.pr + (size_t)r * H + 32 * w + 8 * g + 4 * h);
+        }
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = wave_gemm<16>(Xb, H / 4, 0, wa, j, h, acc);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[4 * g + k] = fmaxf(acc[4 * g + k] + gs[g][k] + gr[g][k], 0.f);
+        acc_to_tile(Hs, acc, w, j, h);
+        __syncthreads();                                                     // (B)
+        acc = acc_from_vec(vec[0], w, h);
+        acc = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, acc);
+        acc = relu16(acc);
+        acc = layernorm_rows(acc, red, w, j, h, vec[1], vec[2]);             // (C), (D)
+        acc_to_tile(Hs, acc, w, j, h);
+        __syncthreads();                                                     // (E)
+        if (w >= 2) {
+            // residual + coalesced store of the new edge latents
+            const int tt = t - 128;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int idx = tt + 128 * it, row = idx >> 5, q = idx & 31;
+                if (row < nvalid) {
+                    const f32x4 y = *(const f32x4*)(Hs + toff(row, q, H / 4));
+                    const f32x4 x = *(const f32x4*)(Xb + toff(row, q, H / 4));
+                    *(f32x4*)(a.e_out + (size_t)(base + row) * H + 4 * q) = y + x;
+                }
+            }
+        } else {
+            // receiver-segmented sum of the pre-residual outputs, one column per thread
+            const int* rr = rid[buf];
+            for (int row = 0; row < nvalid; ++row) {
+                run += Hs[toff(row, t >> 2, H / 4) + (t & 3)];
+                const int cur = rr[row];
+                if (rr[row + 1] != cur) { a.aggr[(size_t)cur * H + t] = run; run = 0.f; }
+            }
+        }
+        // the next iteration stages into the other X / rid buffer; Hs and red are rewritten
+        // only after its barrier (A), which every thread reaches after finishing this pass
+    }
+}
+
+// ======================================================================== processor: nodes
+struct NodeArgs {
+    const float* x; const float* aggr; const int* rowptr;
+    const float* w0; const float* b0; const float* w1; const float* b1; const float* ln_w; const float* ln_b;
+    float* x_out; int n_nodes;
+};
+
+__global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
+    __shared__ __attribute__((aligned(16))) float XA[tile_floats(H / 2)];  // [x | aggr] tile
+    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float vec[4][H];       // b0, b1, ln_w, ln_b
+    __shared__ float red[8 * TM];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    f32x4 wa[32], wb[16];
+    load_wfrag<32>(wa, a.w0, 2 * H, 0, 32 * w + j, h);
+    load_wfrag<16>(wb, a.w1, H, 0, 32 * w + j, h);
+    if (t < H) { vec[0][t] = a.b0[t]; vec[1][t] = a.b1[t]; vec[2][t] = a.ln_w[t]; vec[3][t] = a.ln_b[t]; }
+
+    const int ntiles = (a.n_nodes + TM - 1) / TM;
+    const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+    const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
+    const int srow = t >> 5, sq = t & 31;
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+        const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
+            const f32x4 xv = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+            f32x4 av = {0.f, 0.f, 0.f, 0.f};
+            if (a.rowptr[n + 1] > a.rowptr[n]) av = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
+            *(f32x4*)(XA + toff(row, sq, H / 2)) = xv;
+            *(f32x4*)(XA + toff(row, 32 + sq, H / 2)) = av;
+        }
+        __syncthreads();
+        f32x16 acc = acc_from_vec(vec[0], w, h);
+        acc = wave_gemm<32>(XA, H / 2, 0, wa, j, h, acc);
+        acc = relu16(acc);
+        acc_to_tile(Hs, acc, w, j, h);
+        __syncthreads();
+        acc = acc_from_vec(vec[1], w, h);
+        acc = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, acc);
+        acc = relu16(acc);
+        acc = layernorm_rows(acc, red, w, j, h, vec[2], vec[3]);
+        acc_to_tile(Hs, acc, w, j, h);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            if (row < nvalid) {
+                const f32x4 y = *(const f32x4*)(Hs + toff(row, sq, H / 4));
+                const f32x4 x = *(const f32x4*)(XA + toff(row, sq, H / 2));
+                *(f32x4*)(a.x_out + (size_t)(base + row) * H + 4 * sq) = y + x;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ======================================================================== processor: projections
+struct ProjArgs { const float* x; const float* w0; const float* b0; float* ps; float* pr; int n_nodes; };
+
+__global__ __launch_bounds__(NT, 2) void mp_project_kernel(ProjArgs a) {
+    __shared__ __attribute__((aligned(16))) float X[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float Ps[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float Pr[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float vec[H];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    f32x4 ws[16], wr[16];
+    load_wfrag<16>(ws, a.w0, 3 * H, 0, 32 * w + j, h);
+    load_wfrag<16>(wr, a.w0, 3 * H, H, 32 * w + j, h);
+    if (t < H) vec[t] = a.b0[t];
+
+    const int ntiles = (a.n_nodes + TM - 1) / TM;
+    const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+    const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
+    const int srow = t >> 5, sq = t & 31;
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+        const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
+            *(f32x4*)(X + toff(row, sq, H / 4)) = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+        }
+        __syncthreads();
+        f32x16 as = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 ar = acc_from_vec(vec, w, h);
+        as = wave_gemm<16>(X, H / 4, 0, ws, j, h, as);
+        ar = wave_gemm<16>(X, H / 4, 0, wr, j, h, ar);
+        acc_to_tile(Ps, as, w, j, h);
+        acc_to_tile(Pr, ar, w, j, h);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            if (row < nvalid) {
+                *(f32x4*)(a.ps + (size_t)(base + row) * H + 4 * sq) = *(const f32x4*)(Ps + toff(row, sq, H / 4));
+                *(f32x4*)(a.pr + (size_t)(base + row) * H + 4 * sq) = *(const f32x4*)(Pr + toff(row, sq, H / 4));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ======================================================================== encoder
+struct EncArgs {
+    const float* feat; const float* mean_std;
+    const float* w0; const float* b0; const float* w1; const float* b1; const float* ln_w; const float* ln_b;
+    float* out; int rows; int n_feat;
+};
+
+__global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
+    __shared__ __attribute__((aligned(16))) float Fs[TM * MGN_MAX_FEAT];
+    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float Os[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float vec[3][H];       // b1, ln_w, ln_b
+    __shared__ float ms[2 * MGN_MAX_FEAT];
+    __shared__ float red[8 * TM];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    const int F = a.n_feat;
+    f32x4 wb[16];
+    load_wfrag<16>(wb, a.w1, H, 0, 32 * w + j, h);
+    const int srow = t >> 5, sq = t & 31;
+    // first-layer weights of features 4*sq .. 4*sq+3, zero padded to MGN_MAX_FEAT inputs
+    float w0r[4][MGN_MAX_FEAT], b0r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        b0r[i] = a.b0[4 * sq + i];
+#pragma unroll
+        for (int k = 0; k < MGN_MAX_FEAT; ++k) w0r[i][k] = (k < F) ? a.w0[(size_t)(4 * sq + i) * F + k] : 0.f;
+    }
+    if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; }
+    if (t < MGN_MAX_FEAT) {
+        ms[t] = (a.mean_std && t < F) ? a.mean_std[t] : 0.f;
+        ms[MGN_MAX_FEAT + t] = (a.mean_std && t < F) ? a.mean_std[F + t] : 1.f;
+    }
+    const int ntiles = (a.rows + TM - 1) / TM;
+    const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+    const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+        const int base = tile * TM, nvalid = min(TM, a.rows - base);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = t + NT * it, row = idx >> 4, k = idx & 15;
+            const int n = min(base + row, a.rows - 1);
+            Fs[idx] = (k < F) ? (a.feat[(size_t)n * F + k] - ms[k]) / ms[MGN_MAX_FEAT + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            f32x4 hv = {b0r[0], b0r[1], b0r[2], b0r[3]};
+#pragma unroll
+            for (int k4 = 0; k4 < MGN_MAX_FEAT / 4; ++k4) {
+                const f32x4 f = *(const f32x4*)(Fs + row * MGN_MAX_FEAT + 4 * k4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hv[i] += w0r[i][4 * k4 + k] * f[k];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) hv[i] = fmaxf(hv[i], 0.f);
+            *(f32x4*)(Hs + toff(row, sq, H / 4)) = hv;
+        }
+        __syncthreads();
+        f32x16 acc = acc_from_vec(vec[0], w, h);
+        acc = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, acc);
+        acc = layernorm_rows(acc, red, w, j, h, vec[1], vec[2]);
+        acc_to_tile(Os, acc, w, j, h);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            if (row < nvalid)
+                *(f32x4*)(a.out + (size_t)(base + row) * H + 4 * sq) = *(const f32x4*)(Os + toff(row, sq, H / 4));
+        }
+        // Fs / Hs / Os of the next tile are written only after barriers every thread
+        // reaches after this store pass; red is rewritten after the next Hs barrier
+    }
+}
+
+// ======================================================================== decoder + integrator
+struct DecArgs {
+    const float* x; const float* w0; const float* b0; const float* w1; const float* b1;
+    float* delta_norm; const float* out_mean_std; const float* world_pos; const float* phi; const float* node_type;
+    float* pred; int n_nodes; int time_dim; int out_dim;
+};
+
+__global__ __launch_bounds__(NT, 1) void decode_kernel(DecArgs a) {
+    __shared__ __attribute__((aligned(16))) float X[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float vec[H];
+    __shared__ float ob[MGN_MAX_DEC_OUT], om[MGN_MAX_DEC_OUT], os[MGN_MAX_DEC_OUT];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    const int n_out = a.time_dim * a.out_dim;
+    f32x4 wa[16], wb[16];
+    load_wfrag<16>(wa, a.w0, H, 0, 32 * w + j, h);
+    load_wfrag<16>(wb, a.w1, H, 0, min(j, n_out - 1), h, w == 0 && j < n_out);   // rows >= n_out read as zero
+    if (t < H) vec[t] = a.b0[t];
+    if (t < MGN_MAX_DEC_OUT) {
+        ob[t] = (t < n_out) ? a.b1[t] : 0.f;
+        om[t] = (a.pred && t < n_out) ? a.out_mean_std[t] : 0.f;
+        os[t] = (a.pred && t < n_out) ? a.out_mean_std[n_out + t] : 1.f;
+    }
+    const int ntiles = (a.n_nodes + TM - 1) / TM;
+    const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+    const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
+    const int srow = t >> 5, sq = t & 31;
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+        const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
+            *(f32x4*)(X + toff(row, sq, H / 4)) = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+        }
+        __syncthreads();
+        f32x16 acc = acc_from_vec(vec, w, h);
+        acc = wave_gemm<16>(X, H / 4, 0, wa, j, h, acc);
+        acc = relu16(acc);
+        acc_to_tile(Hs, acc, w, j, h);
+        __syncthreads();
+        if (w == 0) {
+            f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            o = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, o);
+            if (j < nvalid) {
+                const int n = base + j;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int oi = (reg & 3) + 8 * (reg >> 2) + 4 * h;     // decoder output index
+                    if (oi < n_out) {
+                        const int tt = oi / a.out_dim, k = oi - tt * a.out_dim;
+                        const float dn = (o[reg] + ob[oi]) * (float)(tt + 1);
+                        if (a.delta_norm) a.delta_norm[((size_t)tt * a.n_nodes + n) * a.out_dim + k] = dn;
+                        if (a.pred) {
+                            float d = os[oi] * dn + om[oi];
+                            if (a.node_type[(size_t)n * 5 + k + 1] == 1.0f) d = 0.f;
+                            const float cur = (k < 2) ? a.world_pos[(size_t)n * 2 + k] : a.phi[n];
+                            a.pred[((size_t)tt * a.n_nodes + n) * 3 + k] = cur + d;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ======================================================================== features / normaliser
+__global__ void node_features_kernel(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
+                                     const float* __restrict__ phi, const float* __restrict__ swell, int n_swell,
+                                     const float* __restrict__ node_type, const float* __restrict__ mat_param,
+                                     float* __restrict__ feat, int n_nodes) {
+    const int F = 3 + n_swell + 5 + (mat_param ? 2 : 0);
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += gridDim.x * blockDim.x) {
+        float* f = feat + (size_t)n * F;
+        f[0] = world_pos[2 * n] - mesh_pos[2 * n];
+        f[1] = world_pos[2 * n + 1] - mesh_pos[2 * n + 1];
+        f[2] = phi[n];
+        for (int k = 0; k < n_swell; ++k) f[3 + k] = swell[(size_t)n * n_swell + k];
+        for (int k = 0; k < 5; ++k) f[3 + n_swell + k] = node_type[(size_t)n * 5 + k];
+        if (mat_param) { f[8 + n_swell] = mat_param[0]; f[9 + n_swell] = mat_param[1]; }
+    }
+}
+
+__global__ void edge_features_kernel(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
+                                     const float* __restrict__ phi, const int* __restrict__ sender,
+                                     const int* __restrict__ recv, float* __restrict__ feat, int n_edges) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += gridDim.x * blockDim.x) {
+        const int s = sender[e], r = recv[e];
+        const float mx = mesh_pos[2 * s] - mesh_pos[2 * r], my = mesh_pos[2 * s + 1] - mesh_pos[2 * r + 1];
+        const float wx = world_pos[2 * s] - world_pos[2 * r], wy = world_pos[2 * s + 1] - world_pos[2 * r + 1];
+        float* f = feat + (size_t)e * 7;
+        f[0] = mx; f[1] = my; f[2] = sqrtf(mx * mx + my * my);
+        f[3] = wx; f[4] = wy; f[5] = sqrtf(wx * wx + wy * wy);
+        f[6] = phi[s] - phi[r];
+    }
+}
+
+constexpr int SUM_BLOCKS_MAX = 1024;
+
+__global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* __restrict__ feat, long long rows,
+                                                                  int F, double* __restrict__ partial) {
+    __shared__ double sh[NT];
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    double s[MGN_MAX_FEAT], q[MGN_MAX_FEAT];
+#pragma unroll
+    for (int k = 0; k < MGN_MAX_FEAT; ++k) { s[k] = 0.0; q[k] = 0.0; }
+    for (long long r = r0 + threadIdx.x; r < r1; r += NT) {
+#pragma unroll
+        for (int k = 0; k < MGN_MAX_FEAT; ++k)
+            if (k < F) { const double v = feat[r * F + k]; s[k] += v; q[k] += v * v; }
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * MGN_MAX_FEAT; ++k) {
+        const int kk = k % MGN_MAX_FEAT;
+        if (kk >= F) continue;
+        sh[threadIdx.x] = (k < MGN_MAX_FEAT) ? s[kk] : q[kk];
+        __syncthreads();
+        for (int off = NT / 2; off > 0; off >>= 1) {
+            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 2 * MGN_MAX_FEAT + k] = sh[0];
+        __syncthreads();
+    }
+}
+
+__global__ void feature_sums_final_kernel(const double* __restrict__ partial, int nblocks, int F,
+                                          double* __restrict__ sums) {
+    const int k = threadIdx.x;                     // 0 .. 2F-1
+    if (k >= 2 * F) return;
+    const int col = (k < F) ? k : MGN_MAX_FEAT + (k - F);
+    double acc = 0.0;
+    for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * 2 * MGN_MAX_FEAT + col];
+    sums[k] = acc;
+}
+
+__global__ void norm_update_kernel(float* acc_sum, float* acc_sumsq, const double* sums, int F, float safe_count,
+                                   float eps, float* mean_std) {
+    const int k = threadIdx.x;
+    if (k >= F) return;
+    float s = acc_sum[k], q = acc_sumsq[k];
+    if (sums) {
+        s += (float)sums[k]; q += (float)sums[F + k];
+        acc_sum[k] = s; acc_sumsq[k] = q;
+    }
+    const float mean = s / safe_count;
+    const float var = fmaxf(q / safe_count - mean * mean, 0.f);
+    mean_std[k] = mean;
+    mean_std[F + k] = sqrtf(var + eps);
+}
+
+__global__ void normalize_kernel(const float* __restrict__ x, const float* __restrict__ mean_std,
+                                 float* __restrict__ out, long long total, int F, bool inverse) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % F);
+        const float m = mean_std[k], s = mean_std[F + k];
+        out[i] = inverse ? s * x[i] + m : (x[i] - m) / s;
+    }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx,
+                                   float* __restrict__ dst, long long rows, int w4, bool scatter) {
+    const long long total = rows * w4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / w4; const int c = (int)(i - r * w4);
+        const long long o = idx[r];
+        if (scatter) ((f32x4*)dst)[o * w4 + c] = ((const f32x4*)src)[i];
+        else ((f32x4*)dst)[i] = ((const f32x4*)src)[o * w4 + c];
+    }
+}
+
+// ------------------------------------------------------------------------ host helpers
+int num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        hipDeviceProp_t p;
+        cached[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return cached[dev];
+}
+
+// number of workgroups for `ntiles` tiles at `per_cu` resident workgroups per CU;
+// a multiple of 8 whenever it exceeds 8 so the XCD mapping applies
+int grid_for(long long ntiles, int per_cu) {
+    long long g = (long long)num_cus() * per_cu;
+    if (ntiles < g) g = ntiles;
+    if (g > 8) g -= g % 8;
+    return (int)(g < 1 ? 1 : g);
+}
+
+int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mgn_set_error("%s: %s", what, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+bool mlp_ok(const mgn_mlp* m, bool need_ln) {
+    return m && m->w0 && m->b0 && m->w1 && m->b1 && (!need_ln || (m->ln_w && m->ln_b));
+}
+
+}  // namespace
+
+#define MGN_REQUIRE(cond, name)                                             \
+    do { if (!(cond)) { mgn_set_error("%s: bad argument (%s)", name, #cond); return MGN_E_ARG; } } while (0)
+
+extern "C" int mgn_mp_project(const float* x, const float* edge_w0, const float* edge_b0, float* ps, float* pr,
+                              int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_mp_project");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(x && edge_w0 && edge_b0 && ps && pr, "mgn_mp_project");
+    ProjArgs a{x, edge_w0, edge_b0, ps, pr, (int)n_nodes};
+    const int g = grid_for((n_nodes + TM - 1) / TM, 2);
+    hipLaunchKernelGGL(mp_project_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_mp_project");
+}
+
+extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, const int32_t* rowptr,
+                           const int32_t* csr_sender, const int32_t* csr_recv, const mgn_mlp* m, float* e_out,
+                           float* aggr, int64_t n_edges, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31) && n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_mp_edge");
+    if (n_edges == 0) return 0;
+    MGN_REQUIRE(e_in && ps && pr && rowptr && csr_sender && csr_recv && e_out && aggr && mlp_ok(m, true), "mgn_mp_edge");
+    EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
+               e_out, aggr, (int)n_edges, (int)n_nodes};
+    const int g = grid_for((n_edges + TM - 1) / TM, 2);
+    hipLaunchKernelGGL(mp_edge_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_mp_edge");
+}
+
+extern "C" int mgn_mp_node(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* m, float* x_out,
+                           int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_mp_node");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(x && aggr && rowptr && x_out && mlp_ok(m, true), "mgn_mp_node");
+    NodeArgs a{x, aggr, rowptr, m->w0, m->b0, m->w1, m->b1, m->ln_w, m->ln_b, x_out, (int)n_nodes};
+    const int g = grid_for((n_nodes + TM - 1) / TM, 1);
+    hipLaunchKernelGGL(mp_node_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_mp_node");
+}
+
+extern "C" int mgn_node_features(const float* world_pos, const float* mesh_pos, const float* phi,
+                                 const float* swelling_phi, int32_t n_swell, const float* node_type,
+                                 const float* mat_param, float* feat, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && n_swell >= 0, "mgn_node_features");
+    MGN_REQUIRE(3 + n_swell + 5 + (mat_param ? 2 : 0) <= MGN_MAX_FEAT, "mgn_node_features");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(world_pos && mesh_pos && phi && node_type && feat && (n_swell == 0 || swelling_phi), "mgn_node_features");
+    const int g = (int)std::min<int64_t>((n_nodes + NT - 1) / NT, 4096);
+    hipLaunchKernelGGL(node_features_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, world_pos, mesh_pos, phi,
+                       swelling_phi, n_swell, node_type, mat_param, feat, (int)n_nodes);
+    return check_launch("mgn_node_features");
+}
+
+extern "C" int mgn_edge_features(const float* world_pos, const float* mesh_pos, const float* phi,
+                                 const int32_t* csr_sender, const int32_t* csr_recv, float* feat, int64_t n_edges,
+                                 void* stream) {
+    MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31), "mgn_edge_features");
+    if (n_edges == 0) return 0;
+    MGN_REQUIRE(world_pos && mesh_pos && phi && csr_sender && csr_recv && feat, "mgn_edge_features");
+    const int g = (int)std::min<int64_t>((n_edges + NT - 1) / NT, 8192);
+    hipLaunchKernelGGL(edge_features_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, world_pos, mesh_pos, phi,
+                       csr_sender, csr_recv, feat, (int)n_edges);
+    return check_launch("mgn_edge_features");
+}
+
+static int sum_blocks(int64_t rows) {
+    const int64_t b = (rows + 4 * NT - 1) / (4 * NT);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, SUM_BLOCKS_MAX));
+}
+
+extern "C" int64_t mgn_feature_sums_scratch_bytes(int64_t rows, int32_t n_feat) {
+    (void)n_feat;
+    return (int64_t)sum_blocks(rows < 0 ? 0 : rows) * 2 * MGN_MAX_FEAT * (int64_t)sizeof(double);
+}
+
+extern "C" int mgn_feature_sums(const float* feat, int64_t rows, int32_t n_feat, double* sums, void* scratch,
+                                void* stream) {
+    MGN_REQUIRE(rows >= 0 && n_feat > 0 && n_feat <= MGN_MAX_FEAT && sums && scratch, "mgn_feature_sums");
+    MGN_REQUIRE(rows == 0 || feat, "mgn_feature_sums");
+    const int nb = sum_blocks(rows);
+    hipLaunchKernelGGL(feature_sums_partial_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, feat,
+                       (long long)rows, (int)n_feat, (double*)scratch);
+    hipLaunchKernelGGL(feature_sums_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+                       (const double*)scratch, nb, (int)n_feat, sums);
+    return check_launch("mgn_feature_sums");
+}
+
+extern "C" int mgn_norm_update(float* acc_sum, float* acc_sumsq, const double* sums, int32_t n_feat, int64_t count,
+                               float eps, float* mean_std, void* stream) {
+    MGN_REQUIRE(acc_sum && acc_sumsq && mean_std && n_feat > 0 && n_feat <= 64 && count >= 0, "mgn_norm_update");
+    const float safe = (float)(count > 1 ? count : 1);
+    hipLaunchKernelGGL(norm_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc_sum, acc_sumsq, sums,
+                       (int)n_feat, safe, eps, mean_std);
+    return check_launch("mgn_norm_update");
+}
+
+extern "C" int mgn_encode(const float* feat, int32_t n_feat, const float* mean_std, const mgn_mlp* enc, float* out,
+                          int64_t rows, void* stream) {
+    MGN_REQUIRE(rows >= 0 && rows < (1ll << 31) && n_feat > 0 && n_feat <= MGN_MAX_FEAT, "mgn_encode");
+    if (rows == 0) return 0;
+    MGN_REQUIRE(feat && out && mlp_ok(enc, true), "mgn_encode");
+    EncArgs a{feat, mean_std, enc->w0, enc->b0, enc->w1, enc->b1, enc->ln_w, enc->ln_b, out, (int)rows, (int)n_feat};
+    const int g = grid_for((rows + TM - 1) / TM, 2);
+    hipLaunchKernelGGL(encode_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_encode");
+}
+
+extern "C" int mgn_decode(const float* x, const mgn_mlp* dec, int32_t time_dim, int32_t out_dim, float* delta_norm,
+                          const float* out_mean_std, const float* world_pos, const float* phi,
+                          const float* node_type, float* pred, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && time_dim > 0 && out_dim > 0 &&
+                time_dim * out_dim <= MGN_MAX_DEC_OUT, "mgn_decode");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(x && mlp_ok(dec, false) && (delta_norm || pred), "mgn_decode");
+    MGN_REQUIRE(!pred || (out_dim == 3 && out_mean_std && world_pos && phi && node_type), "mgn_decode");
+    DecArgs a{x, dec->w0, dec->b0, dec->w1, dec->b1, delta_norm, out_mean_std, world_pos, phi, node_type,
+              pred, (int)n_nodes, (int)time_dim, (int)out_dim};
+    const int g = grid_for((n_nodes + TM - 1) / TM, 1);
+    hipLaunchKernelGGL(decode_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_decode");
+}
+
+extern "C" int mgn_normalize(const float* x, const float* mean_std, float* out, int64_t rows, int32_t n_feat,
+                             int32_t inverse, void* stream) {
+    MGN_REQUIRE(rows >= 0 && n_feat > 0, "mgn_normalize");
+    if (rows == 0) return 0;
+    MGN_REQUIRE(x && mean_std && out, "mgn_normalize");
+    const int64_t total = rows * n_feat;
+    const int g = (int)std::min<int64_t>((total + NT - 1) / NT, 16384);
+    hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, x, mean_std, out,
+                       (long long)total, (int)n_feat, inverse != 0);
+    return check_launch("mgn_normalize");
+}
+
+static int rows_copy(const float* src, const int64_t* idx, float* dst, int64_t rows, int32_t width, void* stream,
+                     bool scatter, const char* name) {
+    MGN_REQUIRE(rows >= 0 && width > 0 && width % 4 == 0, name);
+    if (rows == 0) return 0;
+    MGN_REQUIRE(src && idx && dst, name);
+    const int64_t total = rows * (width / 4);
+    const int g = (int)std::min<int64_t>((total + NT - 1) / NT, 16384);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, src, (const long long*)idx, dst,
+                       (long long)rows, (int)(width / 4), scatter);
+    return check_launch(name);
+}
+
+extern "C" int mgn_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int32_t width,
+                               void* stream) {
+    return rows_copy(src, idx, dst, rows, width, stream, false, "mgn_gather_rows");
+}
+
+extern "C" int mgn_scatter_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int32_t width,
+                                void* stream) {
+    return rows_copy(src, idx, dst, rows, width, stream, true, "mgn_scatter_rows");
+}

@@ -1,0 +1,130 @@
+"""Edge build and frame construction.
+
+``cells_to_edge_index`` replaces core/datasetclass.py:7-20 of the reference (including
+the PyG ``to_undirected`` call at :19) with the host routine of libmgn_hip.so; the
+result is identical, integer for integer.  ``HydrogelDataset`` keeps the reference's
+``.npz`` schema (core/datasetclass.py:43-55; gt_gen/gt_gen/bending_gen.py:297-306) and
+returns ``MeshGraph`` frames instead of PyG ``Data``.
+"""
+from __future__ import annotations
+
+import os
+from typing import List
+
+import numpy as np
+import torch
+
+from . import ops
+from .graph import MeshGraph
+
+
+def cells_to_edge_index(cells: torch.Tensor) -> torch.Tensor:
+    """Triangular cells [C,3] -> directed, duplicate-free edge_index [2,E] (int64), sorted by
+    (sender, receiver), both directions of every triangle side present."""
+    arr = cells.detach().cpu().numpy() if torch.is_tensor(cells) else np.asarray(cells)
+    ei, _ = ops.cells_to_edge_index_np(arr)
+    return torch.from_numpy(ei)
+
+
+def grid_mesh(nx: int, ny: int, lx: float = 1.0, ly: float = 1.0):
+    """(nx+1)*(ny+1) nodes on [0,lx]x[0,ly], ids row-major (x fastest); each cell split along
+    the diagonal from its lower-left to its upper-right corner.  Returns (pos f32 [N,2], cells i64 [C,3])."""
+    xs = np.linspace(0.0, lx, nx + 1)
+    ys = np.linspace(0.0, ly, ny + 1)
+    pos = np.empty(((nx + 1) * (ny + 1), 2), dtype=np.float32)
+    pos[:, 0] = np.tile(xs, ny + 1)
+    pos[:, 1] = np.repeat(ys, nx + 1)
+    ll = (np.arange(ny)[:, None] * (nx + 1) + np.arange(nx)[None, :]).reshape(-1)
+    cells = np.empty((2 * nx * ny, 3), dtype=np.int64)
+    cells[0::2, 0], cells[0::2, 1], cells[0::2, 2] = ll, ll + 1, ll + nx + 2
+    cells[1::2, 0], cells[1::2, 1], cells[1::2, 2] = ll, ll + nx + 1, ll + nx + 2
+    return pos, cells
+
+
+def synthetic_frames(nx: int, ny: int, n_frames: int = 1, seed: int = 0, lx: float = 1.0, ly: float = 1.0,
+                     time_dim: int = 1) -> List[MeshGraph]:
+    """Seeded synthetic trajectory on a structured mesh with bending-style boundary flags
+    (left column: ux, uy fixed; top row: swelling boundary).  Frame fields follow the
+    reference's frames without targets (core/datasetclass.py:110-118)."""
+    pos, cells = grid_mesh(nx, ny, lx, ly)
+    n = pos.shape[0]
+    gen = torch.Generator().manual_seed(seed)
+    mesh_pos = torch.from_numpy(pos)
+    ids = torch.arange(n)
+    left, top = (ids % (nx + 1)) == 0, (ids // (nx + 1)) == ny
+    node_type = torch.zeros(n, 5)
+    node_type[left, 1] = 1.0
+    node_type[left, 2] = 1.0
+    node_type[top, 4] = 1.0
+    node_type[~(left | top), 0] = 1.0
+    edge_index = cells_to_edge_index(torch.from_numpy(cells))
+    cells_t = torch.from_numpy(cells)
+    mat_param = torch.tensor([0.2, 7.5e-6])
+    world0 = mesh_pos + 1e-3 * torch.randn(n, 2, generator=gen)
+    phi0 = 0.5 + 0.1 * torch.rand(n, 1, generator=gen)
+    frames = []
+    for t in range(n_frames):
+        frames.append(MeshGraph(mesh_pos=mesh_pos, node_type=node_type, mat_param=mat_param, cells=cells_t,
+                                edge_index=edge_index, time=torch.tensor(float(t)),
+                                world_pos=world0 + 1e-5 * t, phi=phi0 + 1e-4 * t,
+                                swelling_phi=(0.35 + 0.002 * t) * node_type[:, 4]))
+    if n_frames == 1:       # single-frame use: give the window the model expects, [N, time_dim + 1]
+        frames[0]["swelling_phi"] = frames[0]["swelling_phi"].unsqueeze(1).repeat(1, time_dim + 1)
+    return frames
+
+
+class HydrogelDataset(torch.utils.data.Dataset):
+    """``.npz`` trajectories -> lists of frames (core/datasetclass.py:22-119): same constructor
+    arguments, same fields per frame, same noise model (:75-89) and multi-step targets (:66-72)."""
+
+    def __init__(self, data_dir, noise_level=None, add_targets=None, split_to_frames=None, time_dim=5):
+        self.data_dir = data_dir
+        self.noise_level = noise_level
+        self.add_targets = add_targets
+        self.split_to_frames = split_to_frames
+        self.time_dim = time_dim
+        self.data_files = [f for f in os.listdir(data_dir) if f.endswith(".npz")]
+
+    def __len__(self):
+        return len(self.data_files)
+
+    def get_name(self, idx):
+        return self.data_files[idx].rstrip(".npz")
+
+    def __getitem__(self, idx):
+        s = np.load(os.path.join(self.data_dir, self.data_files[idx]))
+        f32 = lambda k: torch.tensor(s[k], dtype=torch.float32)
+        mesh_pos = f32("mesh_coords")
+        cells = torch.tensor(s["cells"], dtype=torch.long)
+        edge_index = cells_to_edge_index(cells)
+        node_type = f32("node_type")
+        world_pos = mesh_pos + f32("u_time_series")
+        phi = f32("φ_time_series").unsqueeze(-1)
+        swell = f32("swell_time_series").unsqueeze(-1)
+        time = f32("t")
+        mat_param = torch.tensor([s["chi"].item(), s["diffusivity"].item()], dtype=torch.float32)
+        swell_nodes = node_type[:, 4] == 1
+        swell_full = torch.zeros(phi.shape[0], phi.shape[1])
+        swell_full[:, swell_nodes] = swell.expand(phi.shape[0], int(swell_nodes.sum()))
+        common = dict(mesh_pos=mesh_pos, node_type=node_type, mat_param=mat_param, cells=cells, edge_index=edge_index)
+        if not self.add_targets:
+            return [MeshGraph(**common, time=time[t], world_pos=world_pos[t], phi=phi[t], swelling_phi=swell_full[t])
+                    for t in range(world_pos.shape[0])]
+        td = self.time_dim
+        n_cur = world_pos.shape[0] - td
+        row, col = edge_index
+        frames = []
+        for t in range(n_cur):
+            wp, ph = world_pos[t], phi[t]
+            if self.noise_level and self.noise_level > 0.0:
+                conn = torch.max(torch.norm(mesh_pos[row] - mesh_pos[col], dim=-1))
+                wn = torch.randn_like(wp) * self.noise_level * conn
+                wn[node_type[:, 1] == 1, 0] = 0.0
+                wn[node_type[:, 2] == 1, 1] = 0.0
+                pn = torch.randn_like(ph) * self.noise_level * (torch.max(phi) - torch.min(phi))
+                pn[node_type[:, 3] == 1] = 0.0
+                wp, ph = wp + wn, ph + pn
+            target = torch.cat([world_pos[t + 1: t + 1 + td], phi[t + 1: t + 1 + td]], dim=-1)
+            frames.append(MeshGraph(**common, time=time[t], world_pos=wp, phi=ph,
+                                    swelling_phi=swell_full[t: t + td + 1].T, target=target))
+        return frames

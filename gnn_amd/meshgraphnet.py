@@ -1,0 +1,310 @@
+"""Encode-process-decode MeshGraphNets model on the MI355X HIP kernels.
+
+Public surface and checkpoint layout follow ``core/meshgraphnet.py`` of the reference:
+``MLP`` (:33-45), ``EdgeNodeMessagePassing`` (:46-120) and
+``EncodeProcessDecodeMultiScale`` (:122-332) with ``forward`` / ``loss`` / ``predict`` /
+``save_model`` / ``load_model``.  Parameters sit in the same ``nn.Sequential`` slots, so
+``state_dict`` has the reference's 136 keys and a seeded construction draws the same
+weights.  All arithmetic runs in libmgn_hip.so; there is no PyTorch or CPU fallback, and
+options the kernels do not cover (attention, the coarse multiscale branch) raise.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from ._lib import H
+from .graph import Topology, TopologyCache
+from .normalization import Normalizer, ensure_core_alias, load_normalizer
+
+ensure_core_alias()
+
+
+class KernelMLP(nn.Sequential):
+    """``nn.Sequential`` parameter layout of the reference's MLPs, evaluated by the HIP
+    encoder / decoder kernels.  Only the two-Linear shapes the model uses are supported."""
+
+    def _ln_index(self) -> Optional[int]:
+        for i, m in enumerate(self):
+            if isinstance(m, nn.LayerNorm):
+                return i
+        return None
+
+    def weights(self) -> ops.MlpWeights:
+        key = tuple(p.data_ptr() for p in self.parameters())
+        cached = self.__dict__.get("_mgn_w")
+        if cached is None or cached[0] != key:
+            cached = (key, ops.MlpWeights.from_sequential(self, self._ln_index()))
+            self.__dict__["_mgn_w"] = cached
+        return cached[1]
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        rows = x.reshape(-1, x.shape[-1]).contiguous()
+        w = self.weights()
+        if self._ln_index() is not None and len(self) == 4:          # encoder: Linear ReLU Linear LN
+            out = torch.empty(rows.shape[0], H, dtype=torch.float32, device=rows.device)
+            ops.encode(rows, None, w, out)
+            return out.reshape(*lead, H)
+        if self._ln_index() is None and len(self) == 3:              # decoder: Linear ReLU Linear
+            out = torch.empty(1, rows.shape[0], w.out_dim, dtype=torch.float32, device=rows.device)
+            ops.decode(rows, w, 1, w.out_dim, delta_norm=out)
+            return out.reshape(*lead, w.out_dim)
+        raise NotImplementedError("KernelMLP.forward: only the encoder and decoder shapes run stand-alone; "
+                                  "the processor MLPs run inside EdgeNodeMessagePassing")
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_mgn_w", None)
+        return d
+
+
+def MLP(in_dim, out_dim, hidden_dims=(128, 128), activate_final=False, layer_norm=False):
+    """Factory with the reference's signature (core/meshgraphnet.py:33-45)."""
+    if len(tuple(hidden_dims)) != 1 or hidden_dims[0] != H:
+        raise NotImplementedError(f"MLP: the HIP kernels implement one hidden layer of width {H}, got {hidden_dims}")
+    layers = [nn.Linear(in_dim, H), nn.ReLU(), nn.Linear(H, out_dim)]
+    if activate_final:
+        layers.append(nn.ReLU())
+    if layer_norm:
+        layers.append(nn.LayerNorm(out_dim))
+    return KernelMLP(*layers)
+
+
+class _Workspace:
+    """Device buffers for one (device, N, E) problem size, reused across calls."""
+
+    def __init__(self, device, n, e, node_f):
+        f32 = dict(dtype=torch.float32, device=device)
+        self.key = (str(device), n, e, node_f)
+        self.x = torch.empty(n, H, **f32)
+        self.e = torch.empty(e, H, **f32)
+        self.ps = torch.empty(n, H, **f32)
+        self.pr = torch.empty(n, H, **f32)
+        self.aggr = torch.empty(n, H, **f32)
+        self.node_feat = torch.empty(n, node_f, **f32)
+        self.edge_feat = torch.empty(e, 7, **f32)
+
+
+class EdgeNodeMessagePassing(nn.Module):
+    """One processor block (core/meshgraphnet.py:46-120): edge update from
+    (sender, receiver, edge) latents, receiver-wise sum of the new edge latents, node
+    update, both residuals."""
+
+    def __init__(self, hidden_dim, attention=False):
+        super().__init__()
+        if hidden_dim != H:
+            raise NotImplementedError(f"EdgeNodeMessagePassing: hidden_dim must be {H} for the HIP kernels")
+        if attention:
+            raise NotImplementedError("EdgeNodeMessagePassing: attention=True has no HIP kernel "
+                                      "(every shipped config of the reference sets attention: false)")
+        self.hidden_dim = hidden_dim
+        self.attention = attention
+        self.edge_mlp = KernelMLP(nn.Linear(hidden_dim * 3, hidden_dim), nn.ReLU(),
+                                  nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.LayerNorm(hidden_dim))
+        self.node_mlp = KernelMLP(nn.Linear(hidden_dim * 2, hidden_dim), nn.ReLU(),
+                                  nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.LayerNorm(hidden_dim))
+        self.__dict__["_topo"] = TopologyCache()
+
+    def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr):
+        """In place on ``x`` [N,H] and ``e_csr`` [E,H] (receiver-major edge order)."""
+        ew, nw = self.edge_mlp.weights(), self.node_mlp.weights()
+        ops.mp_project(x, self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps, pr)
+        ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
+        ops.mp_node(x, aggr, topo.rowptr, nw, x)
+
+    def forward(self, node_feat, edge_index, edge_feat):
+        """node_feat [N,H], edge_index [2,E] (row 0 sender, row 1 receiver), edge_feat [E,H]
+        in ``edge_index`` order; returns the updated (node_feat, edge_feat) in the same order."""
+        n, e = node_feat.shape[0], edge_feat.shape[0]
+        if "_topo" not in self.__dict__:
+            self.__dict__["_topo"] = TopologyCache()
+        topo = self.__dict__["_topo"].get(edge_index, n, node_feat.device)
+        x = node_feat.detach().to(torch.float32).contiguous().clone()
+        e_csr = torch.empty(e, H, dtype=torch.float32, device=x.device)
+        ops.gather_rows(edge_feat.detach().to(torch.float32).contiguous(), topo.perm, e_csr)
+        ps, pr, aggr = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        self.step_csr(x, e_csr, topo, ps, pr, aggr)
+        e_out = torch.empty_like(e_csr)
+        ops.scatter_rows(e_csr, topo.perm, e_out)
+        return x, e_out
+
+
+class EncodeProcessDecodeMultiScale(nn.Module):
+    def __init__(self,
+                 node_in_dim,
+                 edge_in_dim,
+                 hidden_size=128,
+                 process_steps=3,
+                 coarse_process_steps=3,
+                 node_out_dim=0,
+                 attention=False,
+                 with_mat_params=True,
+                 sample_ratio=0.5,
+                 time_dim=1,
+                 device="cpu"):
+        super().__init__()
+        if sample_ratio > 0:
+            raise NotImplementedError(
+                "EncodeProcessDecodeMultiScale: sample_ratio > 0 (coarse multiscale branch, core/meshgraphnet.py:"
+                "148-156, :179-194) has no HIP implementation; every shipped config uses sample_ratio: 0.0")
+        if attention:
+            raise NotImplementedError("EncodeProcessDecodeMultiScale: attention=True has no HIP implementation")
+        if hidden_size != H:
+            raise NotImplementedError(f"EncodeProcessDecodeMultiScale: hidden_size must be {H}")
+        if edge_in_dim != 7:
+            raise NotImplementedError("EncodeProcessDecodeMultiScale: edge features are the 7 the reference builds")
+        self.node_encoder = MLP(node_in_dim, hidden_size, hidden_dims=(hidden_size,), layer_norm=True)
+        self.edge_encoder = MLP(edge_in_dim, hidden_size, hidden_dims=(hidden_size,), layer_norm=True)
+        self.attention = attention
+        self.with_mat_params = with_mat_params
+        self.sample_ratio = sample_ratio
+        self.time_dim = time_dim
+        self.node_out_dim = node_out_dim
+        self.process_steps = process_steps
+        self.coarse_process_steps = coarse_process_steps
+        self.processors = nn.ModuleList([EdgeNodeMessagePassing(hidden_size, attention) for _ in range(process_steps)])
+        self.node_decoder = MLP(hidden_size, node_out_dim * time_dim, hidden_dims=(hidden_size,), layer_norm=False)
+        self.device = device
+        self.node_features_normalizer = Normalizer(1, node_in_dim, "node_features_normalizer", device)
+        self.edge_features_normalizer = Normalizer(1, edge_in_dim, "edge_features_normalizer", device)
+        self.output_normalizer = Normalizer(time_dim, node_out_dim, "output_normalizer", device)
+        self.__dict__["_topo"] = TopologyCache()
+        self.__dict__["_ws"] = None
+        self.__dict__["halo"] = None          # set by gnn_amd.partition for mesh-partitioned runs
+
+    # ----------------------------------------------------------------- plumbing
+    def _node_feat_dim(self, graph) -> int:
+        return 3 + graph["swelling_phi"].shape[1] + 5 + (2 if self.with_mat_params else 0)
+
+    def _workspace(self, device, n, e, node_f) -> _Workspace:
+        ws = self.__dict__.get("_ws")
+        if ws is None or ws.key != (str(device), n, e, node_f):
+            ws = _Workspace(device, n, e, node_f)
+            self.__dict__["_ws"] = ws
+        return ws
+
+    def topology(self, graph) -> Topology:
+        if "_topo" not in self.__dict__:
+            self.__dict__["_topo"] = TopologyCache()
+        return self.__dict__["_topo"].get(graph["edge_index"], graph["mesh_pos"].shape[0], graph["mesh_pos"].device)
+
+    @staticmethod
+    def _f32(t: torch.Tensor) -> torch.Tensor:
+        return t.detach().to(torch.float32).contiguous()
+
+    def _encode_process(self, graph):
+        """Features -> normalise (accumulating) -> encode -> process.  Returns the workspace
+        holding the final node latents (core/meshgraphnet.py:175-185)."""
+        dev = graph["mesh_pos"].device
+        if dev.type != "cuda":
+            raise RuntimeError("EncodeProcessDecodeMultiScale runs on the GPU only: move the graph with graph.to('cuda')")
+        if next(self.parameters()).device != dev:
+            raise RuntimeError(f"model parameters are on {next(self.parameters()).device}, graph on {dev}")
+        halo = self.__dict__.get("halo")
+        topo = halo.topology if halo is not None else self.topology(graph)
+        n, e = topo.num_nodes, topo.num_edges
+        node_f = self._node_feat_dim(graph)
+        if node_f != self.node_encoder[0].weight.shape[1]:
+            raise RuntimeError(f"node features have width {node_f} but node_in_dim is {self.node_encoder[0].weight.shape[1]}")
+        ws = self._workspace(dev, n, e, node_f)
+        world, mesh, phi = self._f32(graph["world_pos"]), self._f32(graph["mesh_pos"]), self._f32(graph["phi"])
+        if halo is not None:
+            world, phi = halo.exchange_state(world, phi)
+        mat = self._f32(graph["mat_param"]) if self.with_mat_params else None
+        n_own = halo.num_owned if halo is not None else n
+        ops.node_features(world[:n_own], mesh[:n_own], phi[:n_own], self._f32(graph["swelling_phi"])[:n_own],
+                          self._f32(graph["node_type"])[:n_own], mat, ws.node_feat[:n_own])
+        ops.edge_features(world, mesh, phi, topo.sender, topo.recv, ws.edge_feat)
+        hook_n = halo.sum_hook(n_own) if halo is not None else None
+        hook_e = halo.sum_hook(e) if halo is not None else None
+        ms_n = self.node_features_normalizer.stats_for(ws.node_feat[:n_own], True, hook_n)
+        ops.encode(ws.node_feat[:n_own], ms_n, self.node_encoder.weights(), ws.x[:n_own])
+        ms_e = self.edge_features_normalizer.stats_for(ws.edge_feat, True, hook_e)
+        ops.encode(ws.edge_feat, ms_e, self.edge_encoder.weights(), ws.e)
+        for proc in self.processors:
+            if halo is None:
+                proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr)
+            else:
+                halo.step(proc, ws, topo)
+        return ws, topo
+
+    # ----------------------------------------------------------------- reference API
+    def forward(self, batch):
+        """Normalised per-step deltas [time_dim, N, node_out_dim] (core/meshgraphnet.py:168-211)."""
+        ws, topo = self._encode_process(batch)
+        halo = self.__dict__.get("halo")
+        n = halo.num_owned if halo is not None else topo.num_nodes
+        delta = torch.empty(self.time_dim, n, self.node_out_dim, dtype=torch.float32, device=ws.x.device)
+        ops.decode(ws.x[:n], self.node_decoder.weights(), self.time_dim, self.node_out_dim, delta_norm=delta)
+        return delta
+
+    def predict(self, graph):
+        """Next state(s) [time_dim, N, 3]: decode, de-normalise, zero the deltas of
+        Dirichlet nodes, add to the current state (core/meshgraphnet.py:305-317)."""
+        if self.node_out_dim != 3:
+            raise RuntimeError("predict: node_out_dim must be 3 (world_pos x, y and phi)")
+        with torch.no_grad():
+            ws, topo = self._encode_process(graph)
+            halo = self.__dict__.get("halo")
+            n = halo.num_owned if halo is not None else topo.num_nodes
+            ms_o = self.output_normalizer.stats_for(None, accumulate=False)
+            pred = torch.empty(self.time_dim, n, 3, dtype=torch.float32, device=ws.x.device)
+            ops.decode(ws.x[:n], self.node_decoder.weights(), self.time_dim, 3, out_mean_std=ms_o,
+                       world_pos=self._f32(graph["world_pos"])[:n], phi=self._f32(graph["phi"])[:n],
+                       node_type=self._f32(graph["node_type"])[:n], pred=pred)
+        return pred
+
+    def loss(self, graph):
+        """Masked squared error between the normalised target delta and the prediction
+        (core/meshgraphnet.py:285-304).  The output normaliser accumulates first (:290)."""
+        target = self._f32(graph["target"])
+        cur = torch.cat([self._f32(graph["world_pos"]), self._f32(graph["phi"])], dim=-1)
+        tgt = self.output_normalizer(target - cur)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "loss: the backward kernels are not built yet; call under torch.no_grad() for the forward value")
+        pred = self.forward(graph)
+        err = (pred - tgt) ** 2
+        nt = self._f32(graph["node_type"])
+        parts = []
+        for k in range(3):
+            keep = ~(nt[:, k + 1] == 1)
+            sl = slice(k, k + 1) if k < 2 else slice(2, None)
+            parts.append(torch.mean(torch.sum(torch.sum(err[:, keep, sl], dim=2), dim=1)))
+        return parts[0] + parts[1] + parts[2], parts[0], parts[1], parts[2]
+
+    def save_model(self, path):
+        """Checkpoint layout of the reference (core/meshgraphnet.py:318-324)."""
+        torch.save(self.state_dict(), os.path.join(path, "model_weights.pth"))
+        torch.save(self.output_normalizer, os.path.join(path, "output_normalizer.pth"))
+        torch.save(self.node_features_normalizer, os.path.join(path, "node_features_normalizer.pth"))
+        torch.save(self.edge_features_normalizer, os.path.join(path, "edge_features_normalizer.pth"))
+
+    def load_model(self, path):
+        """Loads the reference's checkpoint directory (core/meshgraphnet.py:326-332).  The
+        weights and the three pickled normalisers are read with the tensor-only unpickler
+        and mapped onto this model's device."""
+        dev = next(self.parameters()).device
+        self.load_state_dict(torch.load(os.path.join(path, "model_weights.pth"), weights_only=True, map_location=dev))
+        self.output_normalizer = load_normalizer(os.path.join(path, "output_normalizer.pth"), dev)
+        self.node_features_normalizer = load_normalizer(os.path.join(path, "node_features_normalizer.pth"), dev)
+        self.edge_features_normalizer = load_normalizer(os.path.join(path, "edge_features_normalizer.pth"), dev)
+
+    def _apply(self, fn, *args, **kwargs):
+        """``.to(device)`` also moves the normaliser statistics, which the reference keeps
+        as plain attributes created on the constructor's ``device``."""
+        super()._apply(fn, *args, **kwargs)
+        try:
+            dev = next(self.parameters()).device
+        except StopIteration:
+            return self
+        for nrm in (self.node_features_normalizer, self.edge_features_normalizer, self.output_normalizer):
+            if nrm._acc_sum.device != dev:
+                nrm.to_device(dev)
+        self.__dict__["_ws"] = None
+        return self

@@ -1,0 +1,170 @@
+"""Online feature normaliser with device-resident statistics.
+
+Mirrors ``core/normalization.py:4-51`` of the reference: same constructor, same attribute
+names (``_acc_sum``, ``_acc_sum_squared``, ``_acc_count``, ``_num_accumulations``,
+``_max_accumulations``, ``_std_epsilon``, ``_name``, ``_device``), same behaviour --
+``forward`` accumulates before it normalises and keeps accumulating in eval mode until
+``_max_accumulations`` updates have been seen.  The sums live on the GPU and are updated
+by ``mgn_feature_sums`` + ``mgn_norm_update``; the counts stay Python ints.
+
+The class pickles under the reference's module path (``core.normalization.Normalizer``)
+so ``save_model`` / ``load_model`` keep the reference's checkpoint layout.
+"""
+from __future__ import annotations
+
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Normalizer(nn.Module):
+    def __init__(self, batch_size, feature_size, name, device, max_accumulations=10 ** 6, std_epsilon=1e-8):
+        super().__init__()
+        self._name = name
+        self._device = device
+        self._max_accumulations = max_accumulations
+        self._std_epsilon = std_epsilon
+        self._acc_count = 0
+        self._num_accumulations = 0
+        self._acc_sum = torch.zeros((batch_size, feature_size), dtype=torch.float, device=device)
+        self._acc_sum_squared = torch.zeros((batch_size, feature_size), dtype=torch.float, device=device)
+
+    # ----------------------------------------------------------------- internals
+    def _work(self):
+        """Per-instance device scratch, created lazily (never pickled)."""
+        w = self.__dict__.get("_mgn_work")
+        dev = self._acc_sum.device
+        if w is None or w["dev"] != dev:
+            f = self._acc_sum.numel()
+            w = {"dev": dev, "mean_std": torch.empty(2 * f, dtype=torch.float32, device=dev),
+                 "sums": torch.empty(2 * f, dtype=torch.float64, device=dev), "scratch": None}
+            self.__dict__["_mgn_work"] = w
+        return w
+
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d.pop("_mgn_work", None)
+        return d
+
+    def _require_device(self):
+        if not self._acc_sum.is_cuda:
+            raise RuntimeError(f"Normalizer '{self._name}': statistics are on {self._acc_sum.device}; the HIP path "
+                               "needs them on a GPU (construct the model with device='cuda' or call to_device)")
+
+    def to_device(self, device):
+        """Moves the statistics (plain attributes, so ``nn.Module.to`` does not see them)."""
+        self._acc_sum = self._acc_sum.to(device)
+        self._acc_sum_squared = self._acc_sum_squared.to(device)
+        self._device = device
+        return self
+
+    def _rows_view(self, batched_data: torch.Tensor) -> torch.Tensor:
+        """[B, n, F] -> [n, B*F] rows whose column sums are the reference's sum over dim 1."""
+        b, n, f = batched_data.shape
+        if (b, f) != tuple(self._acc_sum.shape):
+            raise RuntimeError(f"Normalizer '{self._name}': data [B={b}, n, F={f}] does not match statistics "
+                               f"{tuple(self._acc_sum.shape)}")
+        if b == 1:
+            return batched_data.reshape(n, f)
+        return batched_data.permute(1, 0, 2).reshape(n, b * f)
+
+    def stats_for(self, rows2d: torch.Tensor, accumulate: bool = True, partial_sums_hook=None) -> torch.Tensor:
+        """Updates the statistics from ``rows2d`` [n, B*F] when accumulation is live
+        (core/normalization.py:21-23, :30-37) and returns the device vector
+        ``[mean | std]`` (:39-48) that the fused kernels consume.
+
+        ``partial_sums_hook(sums_f64)`` may reduce the float64 sums across ranks in place
+        before they are folded into the statistics (mesh-partitioned runs); it must also
+        return the global row count."""
+        self._require_device()
+        w = self._work()
+        sums = None
+        if accumulate and self._num_accumulations < self._max_accumulations:
+            n, bf = rows2d.shape
+            need = ops.feature_sums_scratch_bytes(n, bf)
+            if w["scratch"] is None or w["scratch"].numel() * 8 < need:
+                w["scratch"] = torch.empty((need + 7) // 8, dtype=torch.float64, device=rows2d.device)
+            ops.feature_sums(rows2d, w["sums"], w["scratch"])
+            sums = w["sums"]
+            if partial_sums_hook is not None:
+                n = int(partial_sums_hook(sums))
+            self._acc_count += n
+            self._num_accumulations += 1
+        ops.norm_update(self._acc_sum, self._acc_sum_squared, sums, self._acc_count, self._std_epsilon, w["mean_std"])
+        return w["mean_std"]
+
+    # ----------------------------------------------------------------- reference API
+    def forward(self, batched_data, accumulate=True):
+        """Normalizes input data and accumulates statistics (core/normalization.py:19-24)."""
+        b, n, f = batched_data.shape
+        rows = self._rows_view(batched_data.contiguous()).contiguous()
+        ms = self.stats_for(rows, accumulate)
+        out = torch.empty_like(rows)
+        ops.normalize(rows, ms, out, inverse=False)
+        return out.reshape(n, b, f).permute(1, 0, 2).contiguous() if b > 1 else out.reshape(1, n, f)
+
+    def inverse(self, normalized_batch_data):
+        """Inverse transformation (core/normalization.py:26-28)."""
+        b, n, f = normalized_batch_data.shape
+        rows = self._rows_view(normalized_batch_data.contiguous()).contiguous()
+        ms = self.stats_for(rows, accumulate=False)
+        out = torch.empty_like(rows)
+        ops.normalize(rows, ms, out, inverse=True)
+        return out.reshape(n, b, f).permute(1, 0, 2).contiguous() if b > 1 else out.reshape(1, n, f)
+
+    def _accumulate(self, batched_data, node_num=None):
+        rows = self._rows_view(batched_data.contiguous()).contiguous()
+        saved = self._max_accumulations
+        self._max_accumulations = max(saved, self._num_accumulations + 1)   # unconditional, as in the reference
+        try:
+            self.stats_for(rows, accumulate=True)
+        finally:
+            self._max_accumulations = saved
+
+    def _mean(self):
+        ms = self.stats_for(None, accumulate=False)
+        return ms[: self._acc_sum.numel()].reshape(self._acc_sum.shape).clone()
+
+    def _std_with_epsilon(self):
+        ms = self.stats_for(None, accumulate=False)
+        return ms[self._acc_sum.numel():].reshape(self._acc_sum.shape).clone()
+
+    def get_acc_sum(self):
+        return self._acc_sum
+
+
+# The reference pickles whole Normalizer modules (core/meshgraphnet.py:320-322), so the
+# class has to resolve as ``core.normalization.Normalizer`` on both save and load.
+Normalizer.__module__ = "core.normalization"
+
+
+def ensure_core_alias():
+    """Makes ``core.normalization.Normalizer`` importable as this class when no such
+    module is present (i.e. outside the reference's own source tree)."""
+    mod = sys.modules.get("core.normalization")
+    if mod is not None and getattr(mod, "Normalizer", None) is Normalizer:
+        return
+    if mod is None:
+        pkg = sys.modules.get("core")
+        if pkg is None:
+            pkg = types.ModuleType("core")
+            pkg.__path__ = []           # namespace-like: lets ``import core.normalization`` resolve
+            sys.modules["core"] = pkg
+        mod = types.ModuleType("core.normalization")
+        mod.Normalizer = Normalizer
+        sys.modules["core.normalization"] = mod
+        setattr(pkg, "normalization", mod)
+
+
+def load_normalizer(path, device) -> Normalizer:
+    """Reads a pickled normaliser without executing anything from the file: the tensor-only
+    unpickler, with this class as the single extra allowed global."""
+    with torch.serialization.safe_globals([(Normalizer, "core.normalization.Normalizer")]):
+        obj = torch.load(path, map_location=device, weights_only=True)
+    if not isinstance(obj, Normalizer):
+        raise RuntimeError(f"{path} does not hold a Normalizer")
+    return obj.to_device(device)

@@ -1,0 +1,213 @@
+"""Tensor-level wrappers over the C ABI (include/mgn_hip.h).
+
+Every wrapper checks dtype, device, contiguity and shape on the host before the kernel
+is launched, passes raw device pointers and the current HIP stream, and raises
+RuntimeError on any non-zero return code.  torch is used for memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import H, MAX_DEC_OUT, MAX_FEAT, MgnMlp
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype, shape, name: str) -> C.c_void_p:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: tensor must be contiguous")
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and int(d) != int(s) for d, s in zip(t.shape, shape)):
+            raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _opt(t: Optional[torch.Tensor], dtype, shape, name: str) -> C.c_void_p:
+    return C.c_void_p(0) if t is None else _dev(t, dtype, shape, name)
+
+
+class MlpWeights:
+    """Device pointers of one two-Linear MLP; keeps the tensors alive."""
+
+    def __init__(self, w0, b0, w1, b1, ln_w=None, ln_b=None, in_dim=None, out_dim=H):
+        self.tensors = (w0, b0, w1, b1, ln_w, ln_b)
+        in_dim = w0.shape[1] if in_dim is None else in_dim
+        self.in_dim, self.out_dim = int(in_dim), int(out_dim)
+        self.c = MgnMlp(_dev(w0, torch.float32, (H, in_dim), "w0"), _dev(b0, torch.float32, (H,), "b0"),
+                        _dev(w1, torch.float32, (out_dim, H), "w1"), _dev(b1, torch.float32, (out_dim,), "b1"),
+                        _opt(ln_w, torch.float32, (H,), "ln_w"), _opt(ln_b, torch.float32, (H,), "ln_b"))
+
+    @staticmethod
+    def from_sequential(seq, ln_index: Optional[int]) -> "MlpWeights":
+        """seq[0], seq[2] are the Linears; seq[ln_index] the LayerNorm (None if absent)."""
+        ln = seq[ln_index] if ln_index is not None else None
+        return MlpWeights(seq[0].weight.data, seq[0].bias.data, seq[2].weight.data, seq[2].bias.data,
+                          None if ln is None else ln.weight.data, None if ln is None else ln.bias.data,
+                          in_dim=seq[0].weight.shape[1], out_dim=seq[2].weight.shape[0])
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+# --------------------------------------------------------------------------- host: edge build
+def cells_to_edge_index_np(cells: np.ndarray) -> Tuple[np.ndarray, int]:
+    cells = np.ascontiguousarray(np.asarray(cells, dtype=np.int64).reshape(-1, 3))
+    nc = cells.shape[0]
+    cap = max(6 * nc, 1)
+    snd = np.empty(cap, dtype=np.int64)
+    rcv = np.empty(cap, dtype=np.int64)
+    ne, nn = C.c_int64(0), C.c_int64(0)
+    rc = _lib.lib().mgn_cells_to_edge_index(cells.ctypes.data, nc, snd.ctypes.data, rcv.ctypes.data, cap,
+                                            C.addressof(ne), C.addressof(nn))
+    _lib.check(rc, "mgn_cells_to_edge_index")
+    return np.stack([snd[:ne.value], rcv[:ne.value]]), int(nn.value)
+
+
+def receiver_csr_np(edge_index: np.ndarray, num_nodes: int):
+    ei = np.ascontiguousarray(np.asarray(edge_index, dtype=np.int64))
+    if ei.ndim != 2 or ei.shape[0] != 2:
+        raise RuntimeError(f"edge_index must be [2, E], got {ei.shape}")
+    ne = ei.shape[1]
+    snd, rcv = np.ascontiguousarray(ei[0]), np.ascontiguousarray(ei[1])
+    rowptr = np.empty(num_nodes + 1, dtype=np.int32)
+    cs = np.empty(max(ne, 1), dtype=np.int32)
+    cr = np.empty(max(ne, 1), dtype=np.int32)
+    perm = np.empty(max(ne, 1), dtype=np.int64)
+    rc = _lib.lib().mgn_receiver_csr(snd.ctypes.data, rcv.ctypes.data, ne, num_nodes, rowptr.ctypes.data,
+                                     cs.ctypes.data, cr.ctypes.data, perm.ctypes.data)
+    _lib.check(rc, "mgn_receiver_csr")
+    return rowptr, cs[:ne], cr[:ne], perm[:ne]
+
+
+# --------------------------------------------------------------------------- device: processor
+def mp_project(x, w0, b0, ps, pr):
+    n = x.shape[0]
+    rc = _lib.lib().mgn_mp_project(_dev(x, torch.float32, (n, H), "x"), _dev(w0, torch.float32, (H, 3 * H), "edge w0"),
+                                   _dev(b0, torch.float32, (H,), "edge b0"), _dev(ps, torch.float32, (n, H), "ps"),
+                                   _dev(pr, torch.float32, (n, H), "pr"), n, _stream())
+    _lib.check(rc, "mgn_mp_project")
+
+
+def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, aggr):
+    ne, n = e_in.shape[0], ps.shape[0]
+    if mlp.in_dim != 3 * H or mlp.out_dim != H:
+        raise RuntimeError("mp_edge: edge MLP must be 3H -> H -> H")
+    rc = _lib.lib().mgn_mp_edge(_dev(e_in, torch.float32, (ne, H), "e_in"), _dev(ps, torch.float32, (n, H), "ps"),
+                                _dev(pr, torch.float32, (n, H), "pr"), _dev(rowptr, torch.int32, (n + 1,), "rowptr"),
+                                _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
+                                _dev(csr_recv, torch.int32, (ne,), "csr_recv"), mlp.ref(),
+                                _dev(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (n, H), "aggr"),
+                                ne, n, _stream())
+    _lib.check(rc, "mgn_mp_edge")
+
+
+def mp_node(x, aggr, rowptr, mlp: MlpWeights, x_out):
+    n = x.shape[0]
+    if mlp.in_dim != 2 * H or mlp.out_dim != H:
+        raise RuntimeError("mp_node: node MLP must be 2H -> H -> H")
+    rc = _lib.lib().mgn_mp_node(_dev(x, torch.float32, (n, H), "x"), _dev(aggr, torch.float32, (n, H), "aggr"),
+                                _dev(rowptr, torch.int32, (n + 1,), "rowptr"), mlp.ref(),
+                                _dev(x_out, torch.float32, (n, H), "x_out"), n, _stream())
+    _lib.check(rc, "mgn_mp_node")
+
+
+# --------------------------------------------------------------------------- device: features etc.
+def node_features(world_pos, mesh_pos, phi, swelling_phi, node_type, mat_param, feat):
+    n = world_pos.shape[0]
+    ns = swelling_phi.shape[1]
+    f = 3 + ns + 5 + (2 if mat_param is not None else 0)
+    rc = _lib.lib().mgn_node_features(
+        _dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(mesh_pos, torch.float32, (n, 2), "mesh_pos"),
+        _dev(phi, torch.float32, (n, 1), "phi"), _dev(swelling_phi, torch.float32, (n, ns), "swelling_phi"), ns,
+        _dev(node_type, torch.float32, (n, 5), "node_type"), _opt(mat_param, torch.float32, (2,), "mat_param"),
+        _dev(feat, torch.float32, (n, f), "feat"), n, _stream())
+    _lib.check(rc, "mgn_node_features")
+
+
+def edge_features(world_pos, mesh_pos, phi, csr_sender, csr_recv, feat):
+    n, ne = world_pos.shape[0], csr_sender.shape[0]
+    rc = _lib.lib().mgn_edge_features(
+        _dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(mesh_pos, torch.float32, (n, 2), "mesh_pos"),
+        _dev(phi, torch.float32, (n, 1), "phi"), _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
+        _dev(csr_recv, torch.int32, (ne,), "csr_recv"), _dev(feat, torch.float32, (ne, 7), "feat"), ne, _stream())
+    _lib.check(rc, "mgn_edge_features")
+
+
+def feature_sums_scratch_bytes(rows: int, n_feat: int) -> int:
+    return int(_lib.lib().mgn_feature_sums_scratch_bytes(rows, n_feat))
+
+
+def feature_sums(feat, sums, scratch):
+    m, f = feat.shape
+    need = feature_sums_scratch_bytes(m, f)
+    if scratch.numel() * scratch.element_size() < need:
+        raise RuntimeError(f"feature_sums: scratch holds {scratch.numel() * scratch.element_size()} B, needs {need}")
+    rc = _lib.lib().mgn_feature_sums(_dev(feat, torch.float32, (m, f), "feat"), m, f,
+                                     _dev(sums, torch.float64, (2 * f,), "sums"),
+                                     _dev(scratch, scratch.dtype, None, "scratch"), _stream())
+    _lib.check(rc, "mgn_feature_sums")
+
+
+def norm_update(acc_sum, acc_sumsq, sums, count: int, eps: float, mean_std):
+    f = acc_sum.numel()
+    rc = _lib.lib().mgn_norm_update(_dev(acc_sum, torch.float32, None, "acc_sum"),
+                                    _dev(acc_sumsq, torch.float32, None, "acc_sumsq"),
+                                    _opt(sums, torch.float64, (2 * f,), "sums"), f, int(count), float(eps),
+                                    _dev(mean_std, torch.float32, (2 * f,), "mean_std"), _stream())
+    _lib.check(rc, "mgn_norm_update")
+
+
+def normalize(x2d, mean_std, out, inverse: bool = False):
+    m, f = x2d.shape
+    rc = _lib.lib().mgn_normalize(_dev(x2d, torch.float32, (m, f), "x"), _dev(mean_std, torch.float32, (2 * f,), "mean_std"),
+                                  _dev(out, torch.float32, (m, f), "out"), m, f, 1 if inverse else 0, _stream())
+    _lib.check(rc, "mgn_normalize")
+
+
+def encode(feat, mean_std, mlp: MlpWeights, out):
+    m, f = feat.shape
+    if f > MAX_FEAT or mlp.in_dim != f or mlp.out_dim != H:
+        raise RuntimeError(f"encode: feature width {f} (max {MAX_FEAT}) does not match the encoder ({mlp.in_dim} -> {mlp.out_dim})")
+    rc = _lib.lib().mgn_encode(_dev(feat, torch.float32, (m, f), "feat"), f, _opt(mean_std, torch.float32, (2 * f,), "mean_std"),
+                               mlp.ref(), _dev(out, torch.float32, (m, H), "out"), m, _stream())
+    _lib.check(rc, "mgn_encode")
+
+
+def decode(x, mlp: MlpWeights, time_dim: int, out_dim: int, delta_norm=None, out_mean_std=None, world_pos=None,
+           phi=None, node_type=None, pred=None):
+    n = x.shape[0]
+    n_out = time_dim * out_dim
+    if mlp.in_dim != H or mlp.out_dim != n_out or n_out > MAX_DEC_OUT:
+        raise RuntimeError(f"decode: decoder is {mlp.in_dim} -> {mlp.out_dim}, expected {H} -> {n_out} <= {MAX_DEC_OUT}")
+    rc = _lib.lib().mgn_decode(
+        _dev(x, torch.float32, (n, H), "x"), mlp.ref(), time_dim, out_dim,
+        _opt(delta_norm, torch.float32, (time_dim, n, out_dim), "delta_norm"),
+        _opt(out_mean_std, torch.float32, (2 * n_out,), "out_mean_std"), _opt(world_pos, torch.float32, (n, 2), "world_pos"),
+        _opt(phi, torch.float32, (n, 1), "phi"), _opt(node_type, torch.float32, (n, 5), "node_type"),
+        _opt(pred, torch.float32, (time_dim, n, 3), "pred"), n, _stream())
+    _lib.check(rc, "mgn_decode")
+
+
+def gather_rows(src, idx, dst):
+    m, wd = dst.shape
+    rc = _lib.lib().mgn_gather_rows(_dev(src, torch.float32, (None, wd), "src"), _dev(idx, torch.int64, (m,), "idx"),
+                                    _dev(dst, torch.float32, (m, wd), "dst"), m, wd, _stream())
+    _lib.check(rc, "mgn_gather_rows")
+
+
+def scatter_rows(src, idx, dst):
+    m, wd = src.shape
+    rc = _lib.lib().mgn_scatter_rows(_dev(src, torch.float32, (m, wd), "src"), _dev(idx, torch.int64, (m,), "idx"),
+                                     _dev(dst, torch.float32, (None, wd), "dst"), m, wd, _stream())
+    _lib.check(rc, "mgn_scatter_rows")

@@ -1,0 +1,61 @@
+"""Autoregressive rollout with the state kept on the GPU.
+
+Same call and same returned dictionary as ``core/rollout.py:5-59`` of the reference.
+The reference moves the frame to the device on every step (rollout.py:28); here the
+static fields and the whole swelling schedule are uploaded once and each step only
+swaps device pointers.
+"""
+from __future__ import annotations
+
+import torch
+
+from .graph import MeshGraph
+
+
+def rollout(model, data, progress: bool = False):
+    device = model.device
+    time_dim = model.time_dim
+    n_frames = len(data)
+    first = data[0]
+    with torch.no_grad():
+        static = MeshGraph(mesh_pos=first["mesh_pos"], node_type=first["node_type"], mat_param=first["mat_param"],
+                           edge_index=first["edge_index"]).to(device)
+        # swelling schedule [T + time_dim, N], zero past the end (rollout.py:17-26)
+        sched = torch.stack([data[t]["swelling_phi"] for t in range(n_frames)]
+                            + [torch.zeros_like(first["swelling_phi"])] * time_dim).to(device)
+        cur = MeshGraph(**dict(static.items()))
+        cur["world_pos"] = first["world_pos"].to(device).clone()
+        cur["phi"] = first["phi"].to(device).clone()
+        preds = [torch.cat([cur["world_pos"], cur["phi"]], dim=-1).unsqueeze(0)]
+        steps = range(0, n_frames, time_dim)
+        if progress:
+            from tqdm import tqdm
+            steps = tqdm(steps, desc="Rollout")
+        for t in steps:
+            cur["swelling_phi"] = sched[t: t + time_dim + 1].T.contiguous()
+            pred = model.predict(cur)
+            last = pred[-1]
+            cur["world_pos"] = last[:, :2].contiguous()
+            cur["phi"] = last[:, 2:].contiguous()
+            preds.append(pred)
+        rollout_preds = torch.cat(preds, dim=0)[:n_frames]
+        rollout_gts = torch.stack([torch.cat([data[t]["world_pos"], data[t]["phi"]], dim=-1)
+                                   for t in range(n_frames)]).to(device)
+        swelling_phi = torch.stack([data[t]["swelling_phi"] for t in range(n_frames)])
+        error = (rollout_preds - rollout_gts) ** 2
+        rmse_x = torch.sqrt(torch.mean(error[:, :, 0]))
+        rmse_y = torch.sqrt(torch.mean(error[:, :, 1]))
+        rmse_phi = torch.sqrt(torch.mean(error[:, :, 2]))
+    return {
+        "time": torch.tensor([float(data[t]["time"]) for t in range(n_frames)]),
+        "pred": rollout_preds,
+        "gt": rollout_gts,
+        "swelling_phi": swelling_phi,
+        "mat_param": first["mat_param"],
+        "mesh_pos": first["mesh_pos"],
+        "cells": first["cells"],
+        "node_type": first["node_type"],
+        "rmse_x": rmse_x,
+        "rmse_y": rmse_y,
+        "rmse_phi": rmse_phi,
+    }

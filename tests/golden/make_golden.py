@@ -1,0 +1,305 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz.  Runs ONLY in the build container (it imports the
+reference checkout read-only from /root/reference); the fixtures it writes are plain
+input/output data and are what travels to the GPU box.
+
+For every fixture the script first checks that the CPU oracle (oracle/mgn_oracle.py)
+reproduces the imported reference bit for bit, then stores the reference's outputs.
+
+Stand-ins for wheels the reference imports but the image lacks:
+  torch_scatter.scatter_add      zeros(dim_size, H).scatter_add_(0, index, src)  (torch-scatter 2.1.2)
+  torch_geometric.utils.to_undirected   cat reversed edges, sort by row*N+col, unique  (PyG 2.6.1)
+  torch_geometric.{nn,data}      names only (never executed on the shipped configs)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+
+import oracle as O  # noqa: E402
+
+
+def _install_shims():
+    ts = types.ModuleType("torch_scatter")
+
+    def scatter_add(src, index, dim=0, out=None, dim_size=None):
+        n = dim_size if dim_size is not None else int(index.max()) + 1
+        o = src.new_zeros([n, *src.shape[1:]])
+        return o.scatter_add_(0, index.view(-1, *([1] * (src.dim() - 1))).expand_as(src), src)
+
+    ts.scatter_add, ts.scatter_mean, ts.scatter_max = scatter_add, None, None
+    tg = types.ModuleType("torch_geometric")
+    tgn = types.ModuleType("torch_geometric.nn")
+    tgu = types.ModuleType("torch_geometric.utils")
+    tgd = types.ModuleType("torch_geometric.data")
+
+    def to_undirected(edge_index):
+        row, col = edge_index[0], edge_index[1]
+        row, col = torch.cat([row, col]), torch.cat([col, row])
+        n = int(max(row.max(), col.max())) + 1
+        key = torch.unique(row * n + col)
+        return torch.stack([torch.div(key, n, rounding_mode="floor"), key % n])
+
+    tgn.MessagePassing, tgn.knn_graph = object, None
+    tgu.softmax, tgu.to_undirected = None, to_undirected
+    tgd.Data = object
+    tg.nn, tg.utils, tg.data = tgn, tgu, tgd
+    sys.modules.update({"torch_scatter": ts, "torch_geometric": tg, "torch_geometric.nn": tgn,
+                        "torch_geometric.utils": tgu, "torch_geometric.data": tgd})
+
+
+_install_shims()
+sys.path.insert(0, REF)
+from core.meshgraphnet import EncodeProcessDecodeMultiScale, EdgeNodeMessagePassing  # noqa: E402
+from core.normalization import Normalizer as RefNormalizer  # noqa: E402
+from core.datasetclass import cells_to_edge_index as ref_cells_to_edge_index  # noqa: E402
+from core.rollout import rollout as ref_rollout  # noqa: E402
+
+
+class Frame(dict):
+    """Attribute + item access container standing in for a PyG Data frame."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+    def to(self, device):
+        return self
+
+    def __deepcopy__(self, memo):
+        return Frame({k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.items()})
+
+
+def bit_equal(a, b):
+    return a.shape == b.shape and torch.equal(a, b)
+
+
+def load_ref_norm_stats(path):
+    """Reads a reference normaliser pickle without executing anything from it."""
+    class Stub(torch.nn.Module):
+        pass
+    Stub.__module__, Stub.__name__, Stub.__qualname__ = "core.normalization", "Normalizer", "Normalizer"
+    with torch.serialization.safe_globals([(Stub, "core.normalization.Normalizer")]):
+        o = torch.load(path, map_location="cpu", weights_only=True)
+    return (o._acc_sum.clone(), o._acc_sum_squared.clone(), int(o._acc_count), int(o._num_accumulations))
+
+
+def ref_norm_from(stats, batch, feat, name):
+    n = RefNormalizer(batch, feat, name, "cpu")
+    n._acc_sum, n._acc_sum_squared = stats[0].clone(), stats[1].clone()
+    n._acc_count, n._num_accumulations = stats[2], stats[3]
+    return n
+
+
+def oracle_norm_from(stats):
+    return O.NormStats(stats[0].clone(), stats[1].clone(), stats[2], stats[3])
+
+
+def build_ref_model(cfg, seed):
+    torch.manual_seed(seed)
+    m = EncodeProcessDecodeMultiScale(cfg.node_in_dim, cfg.edge_in_dim, hidden_size=cfg.hidden_size,
+                                      process_steps=cfg.process_steps, coarse_process_steps=0,
+                                      node_out_dim=cfg.node_out_dim, attention=False,
+                                      with_mat_params=cfg.with_mat_params, sample_ratio=0.0,
+                                      time_dim=cfg.time_dim, device="cpu")
+    sd = O.init_state_dict(cfg, seed)
+    rsd = m.state_dict()
+    assert list(rsd.keys()) == list(sd.keys()), "state_dict key order differs"
+    for k in sd:
+        assert bit_equal(rsd[k], sd[k]), k
+    return m, sd
+
+
+def norm_stats_arrays(prefix, n):
+    if isinstance(n, O.NormStats):
+        s, q, c, a = n.acc_sum, n.acc_sum_squared, n.acc_count, n.num_accumulations
+    else:
+        s, q, c, a = n._acc_sum, n._acc_sum_squared, n._acc_count, n._num_accumulations
+    return {f"{prefix}_sum": s.numpy().copy(), f"{prefix}_sumsq": q.numpy().copy(),
+            f"{prefix}_count": np.int64(c), f"{prefix}_nacc": np.int64(a)}
+
+
+# --------------------------------------------------------------------------- G1
+def g1_edges():
+    out = {}
+    rng = np.random.default_rng(7)
+    meshes = {"g2x2": O.grid_mesh(2, 2)[1], "g4x3": O.grid_mesh(4, 3)[1], "g32x16": O.grid_mesh(32, 16, 0.08, 0.01)[1]}
+    pos, cells = O.grid_mesh(6, 5)
+    p = rng.permutation(pos.shape[0])
+    irr = p[cells]                      # relabelled node ids
+    irr = irr[rng.permutation(irr.shape[0])]
+    flip = rng.random(irr.shape[0]) < 0.5
+    irr[flip] = irr[flip][:, ::-1]      # mixed orientation
+    meshes["irregular"] = np.ascontiguousarray(irr[:-7])  # drop a few cells: boundary holes
+    meshes["two_tris"] = np.array([[0, 1, 2], [2, 1, 3]], dtype=np.int64)
+    for name, c in meshes.items():
+        ref = ref_cells_to_edge_index(torch.from_numpy(c)).numpy()
+        mine = O.cells_to_edge_index(c)
+        assert ref.dtype == mine.dtype == np.int64 and np.array_equal(ref, mine), name
+        out[f"{name}_cells"] = c
+        out[f"{name}_edge_index"] = ref
+    # hand-checked: two triangles sharing edge (1,2)
+    assert out["two_tris_edge_index"].tolist() == [[0, 0, 1, 1, 1, 2, 2, 2, 3, 3], [1, 2, 0, 2, 3, 0, 1, 3, 1, 2]]
+    np.savez_compressed(os.path.join(HERE, "g1_edges.npz"), **out)
+    print("g1_edges: ok", {k: v.shape for k, v in out.items() if k.endswith("edge_index")})
+
+
+# --------------------------------------------------------------------------- G2
+def g2_mp_layer():
+    cfg = O.OracleConfig(process_steps=2)
+    _, sd = build_ref_model(cfg, 11)
+    ref_model, _ = build_ref_model(cfg, 11)
+    g = O.synthetic_graph(8, 4, seed=3)
+    n, ne = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(n, 128, generator=gen)
+    e = torch.randn(ne, 128, generator=gen)
+    with torch.no_grad():
+        rx, re = ref_model.processors[1](x, g["edge_index"], e)
+        ox, oe = O.mp_layer(sd, 1, x, g["edge_index"], e)
+    assert bit_equal(rx, ox) and bit_equal(re, oe)
+    np.savez_compressed(os.path.join(HERE, "g2_mp_layer.npz"), nx=8, ny=4, graph_seed=3, weight_seed=11,
+                        layer=1, process_steps=2, sd_digest=O.state_dict_digest(sd),
+                        x=x.numpy(), e=e.numpy(), edge_index=g["edge_index"].numpy(),
+                        x_out=rx.numpy(), e_out=re.numpy())
+    print("g2_mp_layer: ok", n, ne)
+
+
+# --------------------------------------------------------------------------- G3/G4/G5 (bending)
+BEND = os.path.join(REF, "selected_model/bending_best/best_model")
+
+
+def bending_setup(seed=0):
+    cfg = O.OracleConfig()  # node 10, edge 7, H 128, 10 steps, T 1, no mat params
+    ref_model, sd = build_ref_model(cfg, seed)
+    stats = {k: load_ref_norm_stats(os.path.join(BEND, f"{f}.pth")) for k, f in
+             (("node", "node_features_normalizer"), ("edge", "edge_features_normalizer"), ("output", "output_normalizer"))}
+    ref_model.node_features_normalizer = ref_norm_from(stats["node"], 1, 10, "node_features_normalizer")
+    ref_model.edge_features_normalizer = ref_norm_from(stats["edge"], 1, 7, "edge_features_normalizer")
+    ref_model.output_normalizer = ref_norm_from(stats["output"], 1, 3, "output_normalizer")
+    norms = {k: oracle_norm_from(v) for k, v in stats.items()}
+    return cfg, ref_model, sd, stats, norms
+
+
+def g3_predict_bending():
+    cfg, ref_model, sd, stats, norms = bending_setup()
+    g = O.synthetic_graph(32, 16, seed=0, lx=0.08, ly=0.01)
+    out = {"nx": 32, "ny": 16, "lx": 0.08, "ly": 0.01, "graph_seed": 0, "weight_seed": 0,
+           "sd_digest": O.state_dict_digest(sd)}
+    for k, s in stats.items():
+        out.update({f"in_{k}_sum": s[0].numpy(), f"in_{k}_sumsq": s[1].numpy(),
+                    f"in_{k}_count": np.int64(s[2]), f"in_{k}_nacc": np.int64(s[3])})
+    for k in ("mesh_pos", "world_pos", "phi", "swelling_phi", "node_type", "mat_param"):
+        out[f"g_{k}"] = g[k].numpy()
+    with torch.no_grad():
+        rf = ref_model.forward(g)
+        of, lat = O.forward(sd, cfg, norms, g, return_latents=True)
+        assert bit_equal(rf, of)
+        rp = ref_model.predict(g)
+        op = O.predict(sd, cfg, norms, g)
+        assert bit_equal(rp, op)
+    for k, rn in (("node", ref_model.node_features_normalizer), ("edge", ref_model.edge_features_normalizer),
+                  ("output", ref_model.output_normalizer)):
+        assert bit_equal(rn._acc_sum, norms[k].acc_sum) and rn._acc_count == norms[k].acc_count
+        assert rn._num_accumulations == norms[k].num_accumulations
+        out.update(norm_stats_arrays(f"out_{k}", rn))
+    out["forward"], out["predict2"] = rf.numpy(), rp.numpy()   # predict2 = result of the 2nd call (stats moved twice)
+    out["x_enc_rowsum"] = lat["x_enc"].double().sum(1).numpy()
+    out["x_proc_rowsum"] = lat["x_proc"].double().sum(1).numpy()
+    np.savez_compressed(os.path.join(HERE, "g3_predict_bending.npz"), **out)
+    print("g3_predict_bending: ok", rp.shape, float(rp.abs().max()))
+
+
+def g3b_small_general():
+    """time_dim = 2, with_mat_params, fresh normalisers, small mesh, 3 steps."""
+    cfg = O.OracleConfig(node_in_dim=2 + 1 + 3 + 5 + 2, process_steps=3, with_mat_params=True, time_dim=2)
+    ref_model, sd = build_ref_model(cfg, 21)
+    norms = O.make_norms(cfg)
+    g = O.synthetic_graph(8, 4, seed=4, time_dim=2, with_target=True)
+    with torch.no_grad():
+        rp1 = ref_model.predict(g); op1 = O.predict(sd, cfg, norms, g)
+        rp2 = ref_model.predict(g); op2 = O.predict(sd, cfg, norms, g)
+    assert bit_equal(rp1, op1) and bit_equal(rp2, op2)
+    rl = ref_model.loss(g); ol = O.loss(sd, cfg, norms, g)
+    for a, b in zip(rl, ol):
+        assert bit_equal(a.detach(), b.detach())
+    out = {"nx": 8, "ny": 4, "graph_seed": 4, "weight_seed": 21, "time_dim": 2, "process_steps": 3,
+           "sd_digest": O.state_dict_digest(sd), "predict1": rp1.numpy(), "predict2": rp2.numpy(),
+           "loss": np.array([float(v.detach()) for v in rl], dtype=np.float64)}
+    for k, rn in (("node", ref_model.node_features_normalizer), ("edge", ref_model.edge_features_normalizer),
+                  ("output", ref_model.output_normalizer)):
+        out.update(norm_stats_arrays(f"out_{k}", rn))
+    np.savez_compressed(os.path.join(HERE, "g3b_small_general.npz"), **out)
+    print("g3b_small_general: ok")
+
+
+def g4_loss_grads():
+    cfg, ref_model, sd, stats, norms = bending_setup()
+    g = O.synthetic_graph(32, 16, seed=1, lx=0.08, ly=0.01, with_target=True)
+    ref_model.zero_grad()
+    rl = ref_model.loss(g)
+    rl[0].backward()
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ol = O.loss(sdg, cfg, norms, g)
+    ol[0].backward()
+    out = {"graph_seed": 1, "weight_seed": 0, "loss": np.array([float(v.detach()) for v in rl], dtype=np.float64)}
+    names, l2, asum = [], [], []
+    for (k, p) in ref_model.named_parameters():
+        # the reference's own backward is not run-to-run reproducible on CPU (threaded
+        # accumulation in the index / scatter backward), so gradients pin to a tolerance
+        rel = float((p.grad - sdg[k].grad).double().norm() / p.grad.double().norm().clamp_min(1e-30))
+        assert rel < 2e-6, (k, rel)
+        names.append(k); l2.append(float(p.grad.double().norm())); asum.append(float(p.grad.double().sum()))
+        if p.grad.numel() <= 128 * 3:
+            out["grad__" + k] = p.grad.numpy().copy()
+    for a, b in zip(rl, ol):
+        assert bit_equal(a.detach(), b.detach())
+    out["grad_names"] = np.array(names); out["grad_l2"] = np.array(l2); out["grad_sum"] = np.array(asum)
+    np.savez_compressed(os.path.join(HERE, "g4_loss_grads.npz"), **out)
+    print("g4_loss_grads: ok", out["loss"])
+
+
+def g5_rollout(T=100):
+    cfg, ref_model, sd, stats, norms = bending_setup()
+    g0 = O.synthetic_graph(32, 16, seed=2, lx=0.08, ly=0.01)
+    n = g0["mesh_pos"].shape[0]
+    gen = torch.Generator().manual_seed(9)
+    # synthetic "ground truth": smooth drift + noise; swelling ramps on the top row
+    t = torch.arange(T, dtype=torch.float32).view(T, 1, 1)
+    world = g0["world_pos"].unsqueeze(0) + 1e-5 * t * torch.randn(1, n, 2, generator=gen)
+    phi = g0["phi"].unsqueeze(0) + 1e-4 * t * torch.rand(1, n, 1, generator=gen)
+    swell = (0.35 + 0.002 * t.view(T, 1)) * g0["node_type"][:, 4].view(1, n)
+    frames = [Frame(mesh_pos=g0["mesh_pos"], node_type=g0["node_type"], mat_param=g0["mat_param"],
+                    cells=g0["cells"], edge_index=g0["edge_index"], time=torch.tensor(float(k)),
+                    world_pos=world[k], phi=phi[k], swelling_phi=swell[k]) for k in range(T)]
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        rr = ref_rollout(ref_model, frames)
+    static = {k: g0[k] for k in ("mesh_pos", "node_type", "mat_param", "edge_index")}
+    op, ormse = O.rollout(sd, cfg, norms, static, world, phi, swell)
+    assert bit_equal(rr["pred"], op)
+    assert bit_equal(torch.stack([rr["rmse_x"], rr["rmse_y"], rr["rmse_phi"]]), ormse)
+    out = {"T": T, "graph_seed": 2, "traj_seed": 9, "weight_seed": 0,
+           "world_pos": world.numpy(), "phi": phi.numpy(), "swelling": swell.numpy(),
+           "pred": rr["pred"].numpy(), "rmse": ormse.numpy()}
+    for k, rn in (("node", ref_model.node_features_normalizer), ("edge", ref_model.edge_features_normalizer)):
+        out.update(norm_stats_arrays(f"out_{k}", rn))
+    np.savez_compressed(os.path.join(HERE, "g5_rollout.npz"), **out)
+    print("g5_rollout: ok", rr["pred"].shape, ormse)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    g1_edges()
+    g2_mp_layer()
+    g3_predict_bending()
+    g3b_small_general()
+    g4_loss_grads()
+    g5_rollout()
+    print("all fixtures written to", HERE)

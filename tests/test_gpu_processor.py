@@ -1,0 +1,93 @@
+"""GPU parity of the processor kernels (mgn_mp_project / mgn_mp_edge / mgn_mp_node) against
+the CPU oracle and the committed golden vector.  Tolerance: rel-L2 <= 1e-5 per
+message-passing step, the bound the build targets for fp32 (measured noise floor of the
+fp32 formulation itself is 2-8e-7)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _model_layer(sd, i, dev):
+    from gnn_amd.meshgraphnet import EdgeNodeMessagePassing
+    m = EdgeNodeMessagePassing(128)
+    m.load_state_dict({k[len(f"processors.{i}."):]: v for k, v in sd.items() if k.startswith(f"processors.{i}.")})
+    return m.to(dev)
+
+
+def test_mp_layer_golden():
+    d = np.load(f"{GOLDEN}/g2_mp_layer.npz")
+    cfg = O.OracleConfig(process_steps=int(d["process_steps"]))
+    sd = O.init_state_dict(cfg, int(d["weight_seed"]))
+    assert abs(O.state_dict_digest(sd) - float(d["sd_digest"])) < 1e-6 * abs(float(d["sd_digest"])), "seeded init differs"
+    dev = torch.device("cuda:0")
+    layer = _model_layer(sd, int(d["layer"]), dev)
+    x, e = torch.from_numpy(d["x"]).to(dev), torch.from_numpy(d["e"]).to(dev)
+    ei = torch.from_numpy(d["edge_index"]).to(dev)
+    xo, eo = layer(x, ei, e)
+    assert rel_l2(xo, torch.from_numpy(d["x_out"])) < TOL
+    assert rel_l2(eo, torch.from_numpy(d["e_out"])) < TOL
+
+
+@pytest.mark.parametrize("nx,ny", [(32, 16), (7, 3), (1, 1), (100, 60)])
+def test_mp_layer_vs_oracle(nx, ny):
+    cfg = O.OracleConfig(process_steps=1)
+    sd = O.init_state_dict(cfg, 5)
+    # non-trivial LayerNorm affine parameters
+    gen = torch.Generator().manual_seed(1)
+    for k in list(sd):
+        if ".4." in k:
+            sd[k] = sd[k] + 0.3 * torch.randn(128, generator=gen)
+    g = O.synthetic_graph(nx, ny, seed=1)
+    n, ne = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
+    x, e = torch.randn(n, 128, generator=gen), torch.randn(ne, 128, generator=gen)
+    with torch.no_grad():
+        rx, re = O.mp_layer(sd, 0, x, g["edge_index"], e)
+    dev = torch.device("cuda:0")
+    layer = _model_layer(sd, 0, dev)
+    xo, eo = layer(x.to(dev), g["edge_index"].to(dev), e.to(dev))
+    assert rel_l2(xo, rx) < TOL, rel_l2(xo, rx)
+    assert rel_l2(eo, re) < TOL, rel_l2(eo, re)
+    # deterministic: a second run is bit-identical (no atomics anywhere)
+    xo2, eo2 = layer(x.to(dev), g["edge_index"].to(dev), e.to(dev))
+    assert torch.equal(xo, xo2) and torch.equal(eo, eo2)
+
+
+def test_mp_layer_irregular_graph():
+    """Directed, asymmetric graph with isolated nodes, a hub of in-degree 300 (several tiles),
+    duplicate edges and unsorted input order."""
+    gen = torch.Generator().manual_seed(3)
+    n = 500
+    snd = torch.randint(0, n, (4000,), generator=gen)
+    rcv = torch.randint(0, n - 50, (4000,), generator=gen)          # nodes n-50.. have no in-edges
+    rcv[:300] = 7                                                    # hub
+    snd[300:310] = snd[310:320]; rcv[300:310] = rcv[310:320]         # duplicates
+    ei = torch.stack([snd, rcv])
+    cfg = O.OracleConfig(process_steps=1)
+    sd = O.init_state_dict(cfg, 6)
+    x, e = torch.randn(n, 128, generator=gen), torch.randn(4000, 128, generator=gen)
+    with torch.no_grad():
+        rx, re = O.mp_layer(sd, 0, x, ei, e)
+    dev = torch.device("cuda:0")
+    xo, eo = _model_layer(sd, 0, dev)(x.to(dev), ei.to(dev), e.to(dev))
+    assert rel_l2(xo, rx) < TOL, rel_l2(xo, rx)
+    assert rel_l2(eo, re) < TOL, rel_l2(eo, re)
+
+
+def test_mp_layer_empty_edges():
+    cfg = O.OracleConfig(process_steps=1)
+    sd = O.init_state_dict(cfg, 6)
+    x = torch.randn(40, 128)
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    e = torch.zeros(0, 128)
+    with torch.no_grad():
+        rx, re = O.mp_layer(sd, 0, x, ei, e)
+    dev = torch.device("cuda:0")
+    xo, eo = _model_layer(sd, 0, dev)(x.to(dev), ei.to(dev), e.to(dev))
+    assert eo.shape == (0, 128)
+    assert rel_l2(xo, rx) < TOL
