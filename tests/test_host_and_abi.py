@@ -1,0 +1,131 @@
+"""CPU: the C-ABI library loads, exports every symbol the header declares, and its host
+routines (edge build, receiver-major CSR) agree with the oracle exactly.  No kernel is
+launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import GOLDEN, ROOT
+
+
+def _lib_or_build():
+    from gnn_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from gnn_amd.csrc.build import build
+        build()
+    return _lib
+
+
+def test_header_symbols_exported():
+    _lib = _lib_or_build()
+    hdr = open(os.path.join(ROOT, "include", "mgn_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(mgn_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 17
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in mgn_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert _lib.lib().mgn_abi_version() == 1
+
+
+def test_cells_to_edge_index_matches_golden_and_oracle():
+    from gnn_amd.datasetclass import cells_to_edge_index
+    d = np.load(f"{GOLDEN}/g1_edges.npz")
+    for name in ("g2x2", "g4x3", "g32x16", "irregular", "two_tris"):
+        ei = cells_to_edge_index(torch.from_numpy(d[f"{name}_cells"]))
+        assert ei.dtype == torch.int64 and np.array_equal(ei.numpy(), d[f"{name}_edge_index"]), name
+    rng = np.random.default_rng(0)
+    for _ in range(5):                                   # random soups of triangles, ids up to 1000
+        cells = rng.integers(0, 1000, size=(rng.integers(1, 400), 3))
+        assert np.array_equal(cells_to_edge_index(torch.from_numpy(cells)).numpy(), O.cells_to_edge_index(cells))
+    assert cells_to_edge_index(torch.zeros(0, 3, dtype=torch.long)).shape == (2, 0)
+
+
+def test_cells_to_edge_index_large_grid():
+    from gnn_amd.datasetclass import cells_to_edge_index, grid_mesh
+    pos, cells = grid_mesh(316, 316)                      # the 100k-node synthetic mesh
+    ei = cells_to_edge_index(torch.from_numpy(cells)).numpy()
+    assert pos.shape[0] == 100489 and ei.shape == (2, 600400)
+    assert np.array_equal(ei, O.cells_to_edge_index(cells))
+    p2, c2 = O.grid_mesh(316, 316)
+    assert np.array_equal(cells, c2) and np.allclose(pos, p2, atol=1e-7)
+
+
+def test_cells_to_edge_index_rejects_negative_ids():
+    from gnn_amd.datasetclass import cells_to_edge_index
+    with pytest.raises(RuntimeError, match="negative"):
+        cells_to_edge_index(torch.tensor([[0, 1, -2]]))
+
+
+def test_receiver_csr_matches_oracle():
+    from gnn_amd import ops
+    rng = np.random.default_rng(1)
+    for n, e in ((1, 0), (5, 3), (50, 400), (1000, 9000)):
+        ei = np.stack([rng.integers(0, n, e), rng.integers(0, n, e)])
+        got = ops.receiver_csr_np(ei, n)
+        exp = O.receiver_csr(ei, n)
+        for a, b in zip(got, exp):
+            assert a.dtype == b.dtype and np.array_equal(a, b)
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.receiver_csr_np(np.array([[0, 5], [1, 1]]), 3)
+
+
+def test_no_cpu_fallback():
+    from gnn_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.mp_project(torch.zeros(4, 128), torch.zeros(128, 384), torch.zeros(128), torch.zeros(4, 128), torch.zeros(4, 128))
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "gnn_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+
+
+def test_state_dict_layout_and_seeded_init():
+    from gnn_amd.meshgraphnet import EncodeProcessDecodeMultiScale
+    cfg = O.OracleConfig()
+    torch.manual_seed(0)
+    m = EncodeProcessDecodeMultiScale(10, 7, hidden_size=128, process_steps=10, coarse_process_steps=0, node_out_dim=3,
+                                      attention=False, with_mat_params=False, sample_ratio=0.0, time_dim=1, device="cpu")
+    sd, ref = m.state_dict(), O.init_state_dict(cfg, 0)
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 136
+    for k in ref:
+        assert torch.equal(sd[k], ref[k]), k
+    assert sum(p.numel() for p in m.parameters()) == 1209987
+
+
+def test_normalizer_pickle_layout(tmp_path):
+    """Saved normalisers carry the reference's class path; the tensor-only unpickler reads them back."""
+    import pickletools, zipfile
+    from gnn_amd.normalization import Normalizer, load_normalizer
+    n = Normalizer(1, 7, "edge_features_normalizer", "cpu")
+    n._acc_sum += 3.0; n._acc_count = 12; n._num_accumulations = 2
+    torch.save(n, tmp_path / "n.pth")
+    with zipfile.ZipFile(tmp_path / "n.pth") as z:
+        pkl = [x for x in z.namelist() if x.endswith("data.pkl")][0]
+        ops_ = [(op.name, arg) for op, arg, _ in pickletools.genops(z.read(pkl))]
+    assert ("GLOBAL", "core.normalization Normalizer") in ops_
+    back = load_normalizer(tmp_path / "n.pth", "cpu")
+    assert back._acc_count == 12 and back._num_accumulations == 2 and torch.equal(back._acc_sum, n._acc_sum)
+    assert back._name == "edge_features_normalizer" and back._max_accumulations == 10 ** 6
+
+
+def test_mesh_graph_container():
+    import copy
+    from gnn_amd.graph import MeshGraph
+    g = MeshGraph(a=torch.zeros(3), k=5)
+    assert g["a"] is g.a and "a" in g and g.k == 5
+    h = copy.deepcopy(g); h.a += 1
+    assert float(g.a.sum()) == 0.0
+    g.b = torch.ones(2); assert g["b"].shape == (2,)
+    assert g.to("cpu")["a"].device.type == "cpu"
