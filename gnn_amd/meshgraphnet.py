@@ -110,12 +110,21 @@ class EdgeNodeMessagePassing(nn.Module):
                                   nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.LayerNorm(hidden_dim))
         self.__dict__["_topo"] = TopologyCache()
 
-    def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr):
-        """In place on ``x`` [N,H] and ``e_csr`` [E,H] (receiver-major edge order)."""
+    def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr, halo=None):
+        """In place on ``x`` [N,H] and ``e_csr`` [E,H] (receiver-major edge order).  With a
+        ``halo`` plan only the first ``halo.num_owned`` rows of ``x`` are owned; the sender
+        projections of the remaining (halo) rows arrive from their owners."""
         ew, nw = self.edge_mlp.weights(), self.node_mlp.weights()
-        ops.mp_project(x, self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps, pr)
-        ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
-        ops.mp_node(x, aggr, topo.rowptr, nw, x)
+        n = x.shape[0] if halo is None else halo.num_owned
+        with ops.timed("mp_project"):
+            ops.mp_project(x[:n], self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps[:n], pr[:n])
+        if halo is not None:
+            with ops.timed("halo_exchange"):
+                halo.exchange_rows(ps)
+        with ops.timed("mp_edge"):
+            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
+        with ops.timed("mp_node"):
+            ops.mp_node(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, x[:n])
 
     def forward(self, node_feat, edge_index, edge_feat):
         """node_feat [N,H], edge_index [2,E] (row 0 sender, row 1 receiver), edge_feat [E,H]
@@ -213,24 +222,26 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             raise RuntimeError(f"node features have width {node_f} but node_in_dim is {self.node_encoder[0].weight.shape[1]}")
         ws = self._workspace(dev, n, e, node_f)
         world, mesh, phi = self._f32(graph["world_pos"]), self._f32(graph["mesh_pos"]), self._f32(graph["phi"])
+        n_own = halo.num_owned if halo is not None else n
         if halo is not None:
+            if mesh.shape[0] != n:
+                raise RuntimeError(f"partitioned run: mesh_pos must hold the {n} local rows [owned | halo]")
+            if world.shape[0] == n_own:            # state fed back from predict(): owned rows only
+                world = torch.cat([world, world.new_empty(n - n_own, 2)])
+                phi = torch.cat([phi, phi.new_empty(n - n_own, 1)])
             world, phi = halo.exchange_state(world, phi)
         mat = self._f32(graph["mat_param"]) if self.with_mat_params else None
-        n_own = halo.num_owned if halo is not None else n
         ops.node_features(world[:n_own], mesh[:n_own], phi[:n_own], self._f32(graph["swelling_phi"])[:n_own],
                           self._f32(graph["node_type"])[:n_own], mat, ws.node_feat[:n_own])
         ops.edge_features(world, mesh, phi, topo.sender, topo.recv, ws.edge_feat)
-        hook_n = halo.sum_hook(n_own) if halo is not None else None
-        hook_e = halo.sum_hook(e) if halo is not None else None
+        hook_n = halo.sum_hook("node") if halo is not None else None
+        hook_e = halo.sum_hook("edge") if halo is not None else None
         ms_n = self.node_features_normalizer.stats_for(ws.node_feat[:n_own], True, hook_n)
         ops.encode(ws.node_feat[:n_own], ms_n, self.node_encoder.weights(), ws.x[:n_own])
         ms_e = self.edge_features_normalizer.stats_for(ws.edge_feat, True, hook_e)
         ops.encode(ws.edge_feat, ms_e, self.edge_encoder.weights(), ws.e)
         for proc in self.processors:
-            if halo is None:
-                proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr)
-            else:
-                halo.step(proc, ws, topo)
+            proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr, halo)
         return ws, topo
 
     # ----------------------------------------------------------------- reference API

@@ -16,6 +16,37 @@ from . import _lib
 from ._lib import H, MAX_DEC_OUT, MAX_FEAT, MgnMlp
 
 
+# Optional per-kernel timing: when a list is installed, every `timed(name)` block appends
+# (name, start_event, end_event) recorded on the current stream.
+_event_log = None
+
+
+def set_event_log(log):
+    """Installs (or with None removes) the list that receives kernel timing events."""
+    global _event_log
+    _event_log = log
+
+
+class timed:
+    __slots__ = ("name", "start")
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _event_log is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _event_log is not None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record()
+            _event_log.append((self.name, self.start, end))
+        return False
+
+
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 

@@ -1,0 +1,141 @@
+"""Mesh partitioning across GPUs: contiguous node ranges + one-hop halo exchange.
+
+Not in the reference (it is single-device).  Rank r owns the nodes
+``[bounds[r], bounds[r+1])`` and every edge whose *receiver* it owns, so the
+receiver-segmented sum and the node update are purely local; the edge update needs the
+sender projection of nodes owned by other ranks -- the halo.  Local node numbering is
+``[owned (global order) | halo (global order)]``; because ranges are contiguous and
+ascending, the halo block is already grouped by owner rank, so an
+``all_to_all_single`` receives straight into it.
+
+Per message-passing step one exchange moves the 128-float sender projections of the
+halo nodes; per rollout step one exchange moves their (world_pos, phi); the normaliser
+sums are all-reduced while accumulation is live.  ``torch.distributed`` (RCCL on GPUs,
+gloo in the CPU tests) does the transport; packing uses ``index_select`` (a copy).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .graph import MeshGraph, Topology
+
+
+def node_bounds(num_nodes: int, world_size: int) -> List[int]:
+    return [(r * num_nodes) // world_size for r in range(world_size + 1)]
+
+
+class HaloPlan:
+    """Everything rank ``rank`` needs to run its share of a partitioned mesh."""
+
+    def __init__(self, edge_index: np.ndarray, num_nodes: int, world_size: int, rank: int):
+        ei = np.asarray(edge_index, dtype=np.int64)
+        self.world_size, self.rank, self.global_nodes, self.global_edges = world_size, rank, int(num_nodes), int(ei.shape[1])
+        self.bounds = node_bounds(num_nodes, world_size)
+        lo, hi = self.bounds[rank], self.bounds[rank + 1]
+        snd, rcv = ei[0], ei[1]
+        owner_of = lambda ids: np.searchsorted(np.asarray(self.bounds[1:]), ids, side="right")
+        mine = (rcv >= lo) & (rcv < hi)
+        self.edge_ids = np.nonzero(mine)[0]                       # global positions of the local edges
+        ls, lr = snd[mine], rcv[mine]
+        outside = (ls < lo) | (ls >= hi)
+        self.halo_ids = np.unique(ls[outside])                    # global ids, ascending => grouped by owner
+        self.num_owned, self.num_halo = hi - lo, int(self.halo_ids.shape[0])
+        self.num_local = self.num_owned + self.num_halo
+        # global -> local ids for the local edges
+        loc_s = np.where(outside, self.num_owned + np.searchsorted(self.halo_ids, ls), ls - lo)
+        self.local_edge_index = np.stack([loc_s, lr - lo]).astype(np.int64)
+        self.local_node_ids = np.concatenate([np.arange(lo, hi, dtype=np.int64), self.halo_ids])
+        halo_owner = owner_of(self.halo_ids)
+        self.recv_counts = [int((halo_owner == q).sum()) for q in range(world_size)]
+        # what every peer q needs from this rank: q's halo nodes that fall into [lo, hi)
+        send_ids, self.send_counts = [], []
+        src_owner = owner_of(snd)
+        dst_owner = owner_of(rcv)
+        for q in range(world_size):
+            if q == rank:
+                self.send_counts.append(0)
+                continue
+            need = np.unique(snd[(dst_owner == q) & (src_owner == rank)])
+            send_ids.append(need - lo)
+            self.send_counts.append(int(need.shape[0]))
+        self.send_local_ids = np.concatenate(send_ids) if send_ids else np.zeros(0, dtype=np.int64)
+        self.topology: Optional[Topology] = None
+        self.send_idx: Optional[torch.Tensor] = None
+        self.group = None
+
+    # ------------------------------------------------------------------ device side
+    def to(self, device, group=None) -> "HaloPlan":
+        """Builds the local receiver-major topology on ``device`` (needs libmgn_hip.so for its
+        host CSR routine) and uploads the send list."""
+        self.topology = Topology(torch.from_numpy(self.local_edge_index), self.num_local, device)
+        self.send_idx = torch.from_numpy(self.send_local_ids).to(device)
+        self.group = group
+        return self
+
+    def local_graph(self, graph) -> MeshGraph:
+        """The rank's slice of a full-mesh frame: per-node tensors restricted to
+        [owned | halo] rows, ``edge_index`` in local ids."""
+        ids = torch.from_numpy(self.local_node_ids)
+        n = self.global_nodes
+        out = MeshGraph()
+        for k, v in graph.items():
+            if k == "edge_index":
+                out[k] = torch.from_numpy(self.local_edge_index)
+            elif k == "target" and torch.is_tensor(v):
+                out[k] = v[:, ids]
+            elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n and k != "cells":
+                out[k] = v[ids]
+            else:
+                out[k] = v
+        return out
+
+    def exchange_rows(self, buf: torch.Tensor) -> torch.Tensor:
+        """``buf`` is [num_local, W]; rows [0, num_owned) are valid.  Fills the halo rows with
+        the owners' values and returns ``buf``."""
+        if self.world_size == 1:
+            return buf
+        send = buf.index_select(0, self.send_idx) if self.send_idx.numel() else buf.new_empty((0, buf.shape[1]))
+        recv = buf[self.num_owned:]
+        dist.all_to_all_single(recv, send, output_split_sizes=self.recv_counts, input_split_sizes=self.send_counts,
+                               group=self.group)
+        return buf
+
+    def exchange_state(self, world_pos: torch.Tensor, phi: torch.Tensor):
+        """Refreshes the halo rows of the per-step state (3 floats per halo node)."""
+        if self.world_size == 1:
+            return world_pos, phi
+        st = torch.cat([world_pos, phi], dim=1).contiguous()
+        self.exchange_rows(st)
+        return st[:, :2].contiguous(), st[:, 2:].contiguous()
+
+    def sum_hook(self, kind: str):
+        """Hook for ``Normalizer.stats_for``: all-reduces the float64 partial sums and returns
+        the global row count (``kind`` is "node" or "edge")."""
+        total = self.global_nodes if kind == "node" else self.global_edges
+
+        def hook(sums: torch.Tensor) -> int:
+            if self.world_size > 1:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+            return total
+        return hook
+
+    def gather_owned(self, local_rows: torch.Tensor) -> torch.Tensor:
+        """All ranks' owned rows concatenated in global node order (for outputs / tests).
+        ``local_rows`` is [num_owned, ...]."""
+        if self.world_size == 1:
+            return local_rows
+        sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world_size)]
+        parts = [local_rows.new_empty((s,) + tuple(local_rows.shape[1:])) for s in sizes]
+        dist.all_gather(parts, local_rows.contiguous(), group=self.group)
+        return torch.cat(parts, dim=0)
+
+
+def attach(model, plan: HaloPlan):
+    """Switches ``model`` to partitioned execution on ``plan`` (``None`` switches back)."""
+    model.__dict__["halo"] = plan
+    model.__dict__["_ws"] = None
+    return model
