@@ -47,17 +47,31 @@ __device__ __forceinline__ void load_wfrag(f32x4 (&w)[KC], const float* __restri
     for (int c = 0; c < KC; ++c) w[c] = valid ? *(const f32x4*)(p + 8 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// acc[feature][row] += W[feature][k] * tile[row][k] over k = 8*KC values starting at chunk qoff
+// acc[feature][row] += W[feature][k] * tile[row][k] over k = 8*KC values starting at chunk qoff.
+// The LDS reads run two chunks ahead of the MFMAs that consume them.
 template <int KC>
 __device__ __forceinline__ f32x16 wave_gemm(const float* tile, int k4, int qoff, const f32x4 (&w)[KC],
                                             int j, int h, f32x16 acc) {
+    const float* p = tile + toff(j, qoff + h, k4);
+    f32x4 a0 = *(const f32x4*)(p), a1 = *(const f32x4*)(p + 8);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // 2 LDS reads
 #pragma unroll
-    for (int c = 0; c < KC; ++c) {
-        const f32x4 a = *(const f32x4*)(tile + toff(j, qoff + 2 * c + h, k4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0], a[0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1], a[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][2], a[2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][3], a[3], acc, 0, 0, 0);
+    for (int c = 0; c < KC; c += 2) {
+        f32x4 n0 = a0, n1 = a1;
+        if (c + 2 < KC) {
+            n0 = *(const f32x4*)(p + 8 * (c + 2)); n1 = *(const f32x4*)(p + 8 * (c + 3));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // next two chunks first ...
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0], a0[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1], a0[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][2], a0[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][3], a0[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][0], a1[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][1], a1[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][2], a1[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][3], a1[3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // ... then the 8 MFMAs of this pair
+        a0 = n0; a1 = n1;
     }
     return acc;
 }
@@ -78,35 +92,60 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
     return v;
 }
 
-// LayerNorm over the 128 features of every tile row (two-pass: mean, then centred
-// variance, biased, eps inside the root).  `red` is LDS float[2][4][TM].  Contains two
-// workgroup barriers; after the first one every wave has finished reading whatever
-// tile fed the accumulators.
-__device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, int j, int h,
-                                                 const float* gamma_lds, const float* beta_lds) {
+// LayerNorm over the 128 features of every tile row.  Each lane holds 16 of a row's
+// features and forms their mean m and centred sum of squares M2 locally (two passes over
+// registers); the 8 (m, M2) pairs of a row (4 waves x 2 lane halves) meet in `red`, LDS
+// float[2][8][TM], and combine exactly as a pooled variance:
+//   mean = avg(m_k),  M2 = sum(M2_k) + 16 * sum((m_k - mean)^2),  var = M2 / 128 (biased).
+// Contains one workgroup barrier; after it every wave has finished reading whatever tile
+// fed the accumulators.
+__device__ __forceinline__ void ln_local_stats(const f32x16& v, float* red, int w, int j, int h) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += v[i];
-    s += __shfl_xor(s, 32);
-    if (h == 0) red[w * TM + j] = s;
-    __syncthreads();
-    const float mean = (red[j] + red[TM + j] + red[2 * TM + j] + red[3 * TM + j]) * (1.0f / H);
+    const float m = s * (1.0f / 16.0f);
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { v[i] -= mean; q += v[i] * v[i]; }
-    q += __shfl_xor(q, 32);
-    if (h == 0) red[4 * TM + w * TM + j] = q;
-    __syncthreads();
-    const float var = (red[4 * TM + j] + red[5 * TM + j] + red[6 * TM + j] + red[7 * TM + j]) * (1.0f / H);
+    for (int i = 0; i < 16; ++i) { const float d = v[i] - m; q += d * d; }
+    red[(2 * w + h) * TM + j] = m;
+    red[8 * TM + (2 * w + h) * TM + j] = q;
+}
+
+__device__ __forceinline__ f32x16 ln_finish(f32x16 v, const float* red, int w, int j, int h,
+                                            const float* gamma_lds, const float* beta_lds) {
+    float mk[8], mean = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mk[k] = red[k * TM + j]; mean += mk[k]; m2 += red[8 * TM + k * TM + j]; }
+    mean *= 0.125f;
+    float between = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float d = mk[k] - mean; between += d * d; }
+    const float var = (m2 + 16.0f * between) * (1.0f / H);
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 ga = *(const f32x4*)(gamma_lds + 32 * w + 8 * g + 4 * h);
         const f32x4 be = *(const f32x4*)(beta_lds + 32 * w + 8 * g + 4 * h);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[4 * g + t] = v[4 * g + t] * rstd * ga[t] + be[t];
+        for (int t = 0; t < 4; ++t) v[4 * g + t] = (v[4 * g + t] - mean) * rstd * ga[t] + be[t];
     }
     return v;
+}
+
+__device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, int j, int h,
+                                                 const float* gamma_lds, const float* beta_lds) {
+    ln_local_stats(v, red, w, j, h);
+    __syncthreads();
+    return ln_finish(v, red, w, j, h, gamma_lds, beta_lds);
+}
+
+// Asynchronous copy of one 512-byte latent row from global memory into an LDS tile row
+// (global_load_lds: no destination registers).  Lanes 0..31 of the calling wave move 16 bytes
+// each; `lds_row` must be wave-uniform.  Completion: the issuing wave's vmcnt, then a barrier.
+__device__ __forceinline__ void dma_row(const float* grow, float* lds_row, int lane) {
+    if (lane < 32)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + 4 * lane),
+                                         (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
 }
 
 // store the accumulator (row j, features 32w..32w+31) into a [TM][H] LDS tile
@@ -130,7 +169,21 @@ __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n,
     return lo;
 }
 
+// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() would also
+// drain the vector-memory counter whenever an LDS-DMA is outstanding, stalling on global
+// stores and prefetches that nobody needs yet.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void wait_vm_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ======================================================================== processor: edges
+// Two 4-wave workgroups per CU (one wave per SIMD each), every workgroup walking its own
+// contiguous, receiver-aligned edge range in 32-edge tiles:
+//   stage   the tile's rows (prefetched into registers during the previous tile) -> X
+//   P1      first product (edge latents x W0[:, 2H:3H]) + gathered node projections, ReLU -> Hs
+//   P2      second product, ReLU, LayerNorm -> Hs (pre-residual edge output)
+//   P3      residual + coalesced store (waves 2,3) / receiver-segmented sum (waves 0,1)
+// fp32 MFMA and the vector ALU do not overlap on a SIMD, so the kernel is tuned for a low
+// instruction count around the 128 MFMAs of a tile rather than for phase overlap.
 struct EdgeArgs {
     const float* e_in; const float* ps; const float* pr;
     const int* rowptr; const int* sender; const int* recv;
@@ -143,8 +196,8 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float X[2][tile_floats(H / 4)];   // staged e_in tile, double buffered
     __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];     // hidden tile, then the edge output
     __shared__ __attribute__((aligned(16))) float vec[3][H];      // b1, ln_w, ln_b
-    __shared__ float red[8 * TM];
-    __shared__ int rid[2][TM + 1];
+    __shared__ float red[16 * TM];
+    __shared__ int rid[2][TM + 4];
     __shared__ int srange[2];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
@@ -170,33 +223,41 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
         const int r = min(e0 + srow + 8 * it, e1 - 1);
         pre[it] = *(const f32x4*)(a.e_in + (size_t)r * H + 4 * sq);
     }
+    int s_nxt = a.sender[min(e0 + j, e1 - 1)], r_nxt = a.recv[min(e0 + j, e1 - 1)];
     float run = 0.f;                            // running segment sum (threads 0..127: one column each)
     int buf = 0;
     for (int base = e0; base < e1; base += TM, buf ^= 1) {
         const int nvalid = min(TM, e1 - base);
+        const bool more = base + TM < e1;
         float* Xb = X[buf];
 #pragma unroll
         for (int it = 0; it < 4; ++it) *(f32x4*)(Xb + toff(srow + 8 * it, sq, H / 4)) = pre[it];
         if (t <= TM) rid[buf][t] = (base + t < e1) ? a.recv[base + t] : -1;
+        const int s = s_nxt, r = r_nxt;
         __syncthreads();                                                     // (A)
-        if (base + TM < e1) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int r = min(base + TM + srow + 8 * it, e1 - 1);
-                pre[it] = *(const f32x4*)(a.e_in + (size_t)r * H + 4 * sq);
-            }
-        }
-        // per-node projections of this lane's edge: sender part and receiver part (+ bias)
-        const int ej = min(base + j, e1 - 1);
-        const int s = a.sender[ej], r = a.recv[ej];
+        // per-node projections of this lane's edge (sender part; receiver part + bias), issued
+        // ahead of the first product and consumed after it
         f32x4 gs[4], gr[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             gs[g] = *(const f32x4*)(a.ps + (size_t)s * H + 32 * w + 8 * g + 4 * h);
             gr[g] = *(const f32x4*)(a.pr + (size_t)r * H + 32 * w + 8 * g + 4 * h);
         }
+        if (more) {
+            const int ej = min(base + TM + j, e1 - 1);
+            s_nxt = a.sender[ej]; r_nxt = a.recv[ej];
+        }
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         acc = wave_gemm<16>(Xb, H / 4, 0, wa, j, h, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {                                  // next tile's rows: in flight during the second product
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int rr = min(base + TM + srow + 8 * it, e1 - 1);
+                pre[it] = *(const f32x4*)(a.e_in + (size_t)rr * H + 4 * sq);
+            }
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -204,30 +265,50 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
         acc_to_tile(Hs, acc, w, j, h);
         __syncthreads();                                                     // (B)
         acc = acc_from_vec(vec[0], w, h);
+        __builtin_amdgcn_sched_barrier(0);
         acc = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, acc);
         acc = relu16(acc);
-        acc = layernorm_rows(acc, red, w, j, h, vec[1], vec[2]);             // (C), (D)
+        acc = layernorm_rows(acc, red, w, j, h, vec[1], vec[2]);             // (C)
         acc_to_tile(Hs, acc, w, j, h);
         __syncthreads();                                                     // (E)
         if (w >= 2) {
             // residual + coalesced store of the new edge latents
             const int tt = t - 128;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int idx = tt + 128 * it, row = idx >> 5, q = idx & 31;
-                if (row < nvalid) {
-                    const f32x4 y = *(const f32x4*)(Hs + toff(row, q, H / 4));
-                    const f32x4 x = *(const f32x4*)(Xb + toff(row, q, H / 4));
-                    *(f32x4*)(a.e_out + (size_t)(base + row) * H + 4 * q) = y + x;
+            for (int half = 0; half < 2; ++half) {
+                f32x4 y[4], x[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = tt + 128 * (4 * half + it), row = idx >> 5, q = idx & 31;
+                    y[it] = *(const f32x4*)(Hs + toff(row, q, H / 4));
+                    x[it] = *(const f32x4*)(Xb + toff(row, q, H / 4));
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int idx = tt + 128 * (4 * half + it), row = idx >> 5, q = idx & 31;
+                    if (row < nvalid) *(f32x4*)(a.e_out + (size_t)(base + row) * H + 4 * q) = y[it] + x[it];
                 }
             }
         } else {
-            // receiver-segmented sum of the pre-residual outputs, one column per thread
+            // receiver-segmented sum of the pre-residual outputs, one column per thread, rows
+            // added strictly in order; LDS reads batched eight rows at a time
             const int* rr = rid[buf];
-            for (int row = 0; row < nvalid; ++row) {
-                run += Hs[toff(row, t >> 2, H / 4) + (t & 3)];
-                const int cur = rr[row];
-                if (rr[row + 1] != cur) { a.aggr[(size_t)cur * H + t] = run; run = 0.f; }
+            const float* col = Hs + t;
+#pragma unroll
+            for (int r0 = 0; r0 < TM; r0 += 8) {
+                if (r0 < nvalid) {
+                    float v[8]; int id[9];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { v[k] = col[(r0 + k) * (H + 4)]; id[k] = rr[r0 + k]; }
+                    id[8] = rr[r0 + 8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        if (r0 + k < nvalid) {
+                            run += v[k];
+                            if (id[k + 1] != id[k]) { a.aggr[(size_t)id[k] * H + t] = run; run = 0.f; }
+                        }
+                    }
+                }
             }
         }
         // the next iteration stages into the other X / rid buffer; Hs and red are rewritten
@@ -246,7 +327,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float XA[tile_floats(H / 2)];  // [x | aggr] tile
     __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float vec[4][H];       // b0, b1, ln_w, ln_b
-    __shared__ float red[8 * TM];
+    __shared__ float red[16 * TM];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     f32x4 wa[32], wb[16];
@@ -355,7 +436,7 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
     __shared__ __attribute__((aligned(16))) float Os[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float vec[3][H];       // b1, ln_w, ln_b
     __shared__ float ms[2 * MGN_MAX_FEAT];
-    __shared__ float red[8 * TM];
+    __shared__ float red[16 * TM];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     const int F = a.n_feat;
@@ -648,6 +729,8 @@ extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, 
     MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31) && n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_mp_edge");
     if (n_edges == 0) return 0;
     MGN_REQUIRE(e_in && ps && pr && rowptr && csr_sender && csr_recv && e_out && aggr && mlp_ok(m, true), "mgn_mp_edge");
+    // node rows are addressed with 32-bit element offsets
+    MGN_REQUIRE(n_nodes * (int64_t)H < (1ll << 31), "mgn_mp_edge");
     EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
                e_out, aggr, (int)n_edges, (int)n_nodes};
     const int g = grid_for((n_edges + TM - 1) / TM, 2);
