@@ -1,0 +1,144 @@
+"""CPU: node-range partition + one-hop halo plan (gnn_amd/partition.py).  Single-process
+invariants for several rank counts, and a 2-rank gloo run in which each rank evaluates its
+share of the mesh with oracle arithmetic through the plan's exchanges; the gathered result
+must equal the oracle's full-mesh forward."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as F
+
+import oracle as O
+from conftest import rel_l2
+
+
+def _plans(nx, ny, world):
+    from gnn_amd.partition import HaloPlan
+    g = O.synthetic_graph(nx, ny, seed=3)
+    ei = g["edge_index"].numpy()
+    n = g["mesh_pos"].shape[0]
+    return g, ei, n, [HaloPlan(ei, n, world, r) for r in range(world)]
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+def test_plan_invariants(world):
+    g, ei, n, plans = _plans(20, 13, world)
+    owned_edges = np.concatenate([p.edge_ids for p in plans])
+    assert np.array_equal(np.sort(owned_edges), np.arange(ei.shape[1]))          # every edge exactly once
+    assert sum(p.num_owned for p in plans) == n
+    for r, p in enumerate(plans):
+        lo, hi = p.bounds[r], p.bounds[r + 1]
+        assert np.all((ei[1][p.edge_ids] >= lo) & (ei[1][p.edge_ids] < hi))       # edges live with their receiver
+        assert np.all((p.halo_ids < lo) | (p.halo_ids >= hi)) and np.all(np.diff(p.halo_ids) > 0)
+        # local ids map back to the global edge list
+        back = p.local_node_ids[p.local_edge_index]
+        assert np.array_equal(back, ei[:, p.edge_ids])
+        assert p.recv_counts[r] == 0 and p.send_counts[r] == 0 and sum(p.recv_counts) == p.num_halo
+        for q, pq in enumerate(plans):                                            # what r sends to q is what q expects from r
+            assert p.send_counts[q] == pq.recv_counts[r]
+        if world == 1:
+            assert p.num_halo == 0
+    # the rows rank r sends to q are exactly q's halo rows owned by r, in q's halo order
+    for r, p in enumerate(plans):
+        off = 0
+        for q, pq in enumerate(plans):
+            ids = p.send_local_ids[off: off + p.send_counts[q]] + p.bounds[r]
+            off += p.send_counts[q]
+            exp = pq.halo_ids[(pq.halo_ids >= p.bounds[r]) & (pq.halo_ids < p.bounds[r + 1])]
+            assert np.array_equal(ids, exp)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def _partitioned_forward(sd, cfg, norms, plan, gl):
+    """Oracle arithmetic (float64) on one rank's share, in the product's formulation: per-node
+    projections, halo exchange of the sender projections, receiver-major local edges."""
+    H, n_own = cfg.hidden_size, plan.num_owned
+    d = lambda k: sd[k].double()
+    world, phi = plan.exchange_state(gl["world_pos"].clone(), gl["phi"].clone())
+    li = torch.from_numpy(plan.local_edge_index)
+    gg = dict(gl.items()); gg["world_pos"], gg["phi"], gg["edge_index"] = world, phi, li
+    x = O.node_features(cfg, {k: (v[:n_own] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == plan.num_local else v)
+                              for k, v in gg.items()}).unsqueeze(0)
+    e = O.edge_features(gg).unsqueeze(0)
+
+    def normalize(st, data, kind):
+        sums = torch.cat([data.double().sum(1).reshape(-1), (data.double() ** 2).sum(1).reshape(-1)])
+        total = plan.sum_hook(kind)(sums)
+        f = data.shape[2]
+        st.acc_sum = st.acc_sum + sums[:f].float().reshape(1, f)
+        st.acc_sum_squared = st.acc_sum_squared + sums[f:].float().reshape(1, f)
+        st.acc_count += total; st.num_accumulations += 1
+        return (data - st.mean().unsqueeze(1)) / st.std().unsqueeze(1)
+
+    xh = O.mlp(sd, "node_encoder", normalize(norms["node"], x, "node"), final_relu=False, layer_norm=True).squeeze(0).double()
+    eh = O.mlp(sd, "edge_encoder", normalize(norms["edge"], e, "edge"), final_relu=False, layer_norm=True).squeeze(0).double()
+    s, r = li[0], li[1]
+    for i in range(cfg.process_steps):
+        p = f"processors.{i}"
+        W1 = d(f"{p}.edge_mlp.0.weight")
+        ps = torch.zeros(plan.num_local, H, dtype=torch.float64)
+        ps[:n_own] = xh @ W1[:, :H].T
+        plan.exchange_rows(ps)                                    # halo rows arrive from their owners
+        pr = xh @ W1[:, H:2 * H].T + d(f"{p}.edge_mlp.0.bias")
+        h1 = F.relu(ps[s] + pr[r] + eh @ W1[:, 2 * H:].T)
+        h2 = F.relu(F.linear(h1, d(f"{p}.edge_mlp.2.weight"), d(f"{p}.edge_mlp.2.bias")))
+        en = F.layer_norm(h2, (H,), d(f"{p}.edge_mlp.4.weight"), d(f"{p}.edge_mlp.4.bias"), 1e-5)
+        aggr = torch.zeros(n_own, H, dtype=torch.float64).index_add_(0, r, en)
+        gx = F.relu(F.linear(torch.cat([xh, aggr], -1), d(f"{p}.node_mlp.0.weight"), d(f"{p}.node_mlp.0.bias")))
+        gx = F.relu(F.linear(gx, d(f"{p}.node_mlp.2.weight"), d(f"{p}.node_mlp.2.bias")))
+        xh = F.layer_norm(gx, (H,), d(f"{p}.node_mlp.4.weight"), d(f"{p}.node_mlp.4.bias"), 1e-5) + xh
+        eh = en + eh
+    dec = F.linear(F.relu(F.linear(xh, d("node_decoder.0.weight"), d("node_decoder.0.bias"))),
+                   d("node_decoder.2.weight"), d("node_decoder.2.bias"))
+    return dec.view(-1, cfg.time_dim, cfg.node_out_dim).permute(1, 0, 2).float()
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnn_amd.graph import MeshGraph
+        from gnn_amd.partition import HaloPlan
+        torch.set_num_threads(2)
+        cfg = O.OracleConfig(process_steps=3)
+        sd = O.init_state_dict(cfg, 4)
+        g = O.synthetic_graph(17, 11, seed=6)
+        n = g["mesh_pos"].shape[0]
+        plan = HaloPlan(g["edge_index"].numpy(), n, world, rank).to("cpu")
+        assert plan.topology.num_nodes == plan.num_local and plan.topology.num_edges == len(plan.edge_ids)
+        gl = plan.local_graph(MeshGraph(**g))
+        assert gl["mesh_pos"].shape[0] == plan.num_local and gl["edge_index"].shape[1] == len(plan.edge_ids)
+        # stale halo state on purpose: the exchange must refresh it
+        gl["world_pos"][plan.num_owned:] = 123.0
+        gl["phi"][plan.num_owned:] = -7.0
+        norms = O.make_norms(cfg)
+        local = _partitioned_forward(sd, cfg, norms, plan, gl)
+        full = plan.gather_owned(local.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
+        if rank == 0:
+            ref_norms = O.make_norms(cfg)
+            with torch.no_grad():
+                ref = O.forward(sd, cfg, ref_norms, g)
+            ret["rel"] = rel_l2(full, ref)
+            ret["count_ok"] = (norms["node"].acc_count == ref_norms["node"].acc_count and
+                               norms["edge"].acc_count == ref_norms["edge"].acc_count)
+            ret["sum_rel"] = rel_l2(norms["edge"].acc_sum_squared, ref_norms["edge"].acc_sum_squared)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_halo_exchange_matches_full_mesh():
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret["count_ok"]
+    assert ret["sum_rel"] < 1e-6
+    assert ret["rel"] < 2e-5, ret["rel"]
