@@ -169,7 +169,10 @@ def main():
                                "traffic": None, "avg_launch_ms": kern_ms["mp_edge"],
                                "flop_per_edge": FLOP_PER_EDGE_EDGE_KERNEL,
                                "hbm_GBs_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e9}
-            t_mp = sum(kern_ms.get(k, 0.0) for k in ("mp_project", "halo_exchange", "mp_edge", "mp_node")) * 1e-3
+            # one MP step = everything the processor launches for one layer; the projection of
+            # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
+            n_layers = args.steps * args.mp_steps
+            t_mp = sum(sum(per.get(k, [])) for k in ("mp_project", "halo_exchange", "mp_edge", "mp_node")) * 1e-3 / n_layers
             canon = (FLOP_PER_EDGE_CANONICAL * e_local + FLOP_PER_NODE_CANONICAL * n_local) / t_mp / 1e12
             out["mp_step"] = {"ms": t_mp * 1e3, "edge_updates_per_s_per_gpu": e_local / t_mp,
                               "edge_updates_per_s": e / t_mp,

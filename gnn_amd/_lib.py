@@ -31,6 +31,7 @@ SIGNATURES = {
     "mgn_mp_project": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P]),
     "mgn_mp_edge": (C.c_int, [_P, _P, _P, _P, _P, _P, _MLP, _P, _P, _I64, _I64, _P]),
     "mgn_mp_node": (C.c_int, [_P, _P, _P, _MLP, _P, _I64, _P]),
+    "mgn_mp_node_project": (C.c_int, [_P, _P, _P, _MLP, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_node_features": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),
     "mgn_edge_features": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_feature_sums_scratch_bytes": (_I64, [_I64, _I32]),

@@ -317,41 +317,69 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
 }
 
 // ======================================================================== processor: nodes
+// Node update, optionally followed by the NEXT layer's per-node projections of the freshly
+// updated latents (PROJ): one 4-wave workgroup per CU, all five weight slices in registers
+// (the unified 512-entry file at one wave per SIMD), next tile's rows prefetched into
+// registers during the products.
 struct NodeArgs {
     const float* x; const float* aggr; const int* rowptr;
     const float* w0; const float* b0; const float* w1; const float* b1; const float* ln_w; const float* ln_b;
-    float* x_out; int n_nodes;
+    const float* nw0; const float* nb0;          // next layer's first edge Linear [H][3H] and bias (PROJ)
+    float* x_out; float* ps; float* pr; int n_nodes;
 };
 
+template <bool PROJ>
 __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float XA[tile_floats(H / 2)];  // [x | aggr] tile
-    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];
-    __shared__ __attribute__((aligned(16))) float vec[4][H];       // b0, b1, ln_w, ln_b
+    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];  // hidden tile, then the new x
+    __shared__ __attribute__((aligned(16))) float Ps[PROJ ? tile_floats(H / 4) : 4];
+    __shared__ __attribute__((aligned(16))) float Pr[PROJ ? tile_floats(H / 4) : 4];
+    __shared__ __attribute__((aligned(16))) float vec[5][H];       // b0, b1, ln_w, ln_b, next b0
     __shared__ float red[16 * TM];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
-    f32x4 wa[32], wb[16];
+    f32x4 wa[32], wb[16], ws[16], wr[16];
     load_wfrag<32>(wa, a.w0, 2 * H, 0, 32 * w + j, h);
     load_wfrag<16>(wb, a.w1, H, 0, 32 * w + j, h);
-    if (t < H) { vec[0][t] = a.b0[t]; vec[1][t] = a.b1[t]; vec[2][t] = a.ln_w[t]; vec[3][t] = a.ln_b[t]; }
-
+    if constexpr (PROJ) {
+        load_wfrag<16>(ws, a.nw0, 3 * H, 0, 32 * w + j, h);
+        load_wfrag<16>(wr, a.nw0, 3 * H, H, 32 * w + j, h);
+    }
+    if (t < H) {
+        vec[0][t] = a.b0[t]; vec[1][t] = a.b1[t]; vec[2][t] = a.ln_w[t]; vec[3][t] = a.ln_b[t];
+        vec[4][t] = PROJ ? a.nb0[t] : 0.f;
+    }
     const int ntiles = (a.n_nodes + TM - 1) / TM;
     const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
     const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
+    if (t0 >= t1) return;
     const int srow = t >> 5, sq = t & 31;
+    const int nlast = a.n_nodes - 1;
+
+    f32x4 px[4], pa[4];
+    auto prefetch = [&](int tile) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = min(tile * TM + srow + 8 * it, nlast);
+            px[it] = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+            // aggr rows of nodes without in-edges were never written: read them as zero
+            const bool has = a.rowptr[n + 1] > a.rowptr[n];
+            const f32x4 av = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
+            pa[it] = has ? av : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    prefetch(t0);
     __syncthreads();
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
-            const f32x4 xv = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
-            f32x4 av = {0.f, 0.f, 0.f, 0.f};
-            if (a.rowptr[n + 1] > a.rowptr[n]) av = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
-            *(f32x4*)(XA + toff(row, sq, H / 2)) = xv;
-            *(f32x4*)(XA + toff(row, 32 + sq, H / 2)) = av;
+            *(f32x4*)(XA + toff(srow + 8 * it, sq, H / 2)) = px[it];
+            *(f32x4*)(XA + toff(srow + 8 * it, 32 + sq, H / 2)) = pa[it];
         }
         __syncthreads();
+        prefetch(min(tile + 1, t1 - 1));
+        __builtin_amdgcn_sched_barrier(0);
         f32x16 acc = acc_from_vec(vec[0], w, h);
         acc = wave_gemm<32>(XA, H / 2, 0, wa, j, h, acc);
         acc = relu16(acc);
@@ -360,19 +388,39 @@ __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
         acc = acc_from_vec(vec[1], w, h);
         acc = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, acc);
         acc = relu16(acc);
-        acc = layernorm_rows(acc, red, w, j, h, vec[2], vec[3]);
+        acc = layernorm_rows(acc, red, w, j, h, vec[2], vec[3]);     // barrier inside: Hs reads are done
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                                // residual, in accumulator layout
+            const f32x4 xr = *(const f32x4*)(XA + toff(j, 8 * w + 2 * g + h, H / 2));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[4 * g + k] += xr[k];
+        }
         acc_to_tile(Hs, acc, w, j, h);
         __syncthreads();
+        if constexpr (PROJ) {
+            f32x16 as = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 ar = acc_from_vec(vec[4], w, h);
+            as = wave_gemm<16>(Hs, H / 4, 0, ws, j, h, as);
+            ar = wave_gemm<16>(Hs, H / 4, 0, wr, j, h, ar);
+            acc_to_tile(Ps, as, w, j, h);
+            acc_to_tile(Pr, ar, w, j, h);
+            __syncthreads();
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it;
             if (row < nvalid) {
-                const f32x4 y = *(const f32x4*)(Hs + toff(row, sq, H / 4));
-                const f32x4 x = *(const f32x4*)(XA + toff(row, sq, H / 2));
-                *(f32x4*)(a.x_out + (size_t)(base + row) * H + 4 * sq) = y + x;
+                const size_t o = (size_t)(base + row) * H + 4 * sq;
+                *(f32x4*)(a.x_out + o) = *(const f32x4*)(Hs + toff(row, sq, H / 4));
+                if constexpr (PROJ) {
+                    *(f32x4*)(a.ps + o) = *(const f32x4*)(Ps + toff(row, sq, H / 4));
+                    *(f32x4*)(a.pr + o) = *(const f32x4*)(Pr + toff(row, sq, H / 4));
+                }
             }
         }
-        __syncthreads();
+        // XA is rewritten at the top of the next iteration: every thread has passed the last
+        // barrier above after its final XA read; Hs / Ps / Pr are rewritten only after the
+        // next iteration's first barrier, which follows this store pass in program order
     }
 }
 
@@ -738,15 +786,31 @@ extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, 
     return check_launch("mgn_mp_edge");
 }
 
+static int launch_node(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* m,
+                       const float* next_w0, const float* next_b0, float* x_out, float* ps, float* pr,
+                       int64_t n_nodes, void* stream, const char* name) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), name);
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(x && aggr && rowptr && x_out && mlp_ok(m, true), name);
+    NodeArgs a{x, aggr, rowptr, m->w0, m->b0, m->w1, m->b1, m->ln_w, m->ln_b, next_w0, next_b0, x_out, ps, pr,
+               (int)n_nodes};
+    const int g = grid_for((n_nodes + TM - 1) / TM, 1);
+    if (next_w0) hipLaunchKernelGGL((mp_node_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mp_node_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch(name);
+}
+
 extern "C" int mgn_mp_node(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* m, float* x_out,
                            int64_t n_nodes, void* stream) {
-    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_mp_node");
-    if (n_nodes == 0) return 0;
-    MGN_REQUIRE(x && aggr && rowptr && x_out && mlp_ok(m, true), "mgn_mp_node");
-    NodeArgs a{x, aggr, rowptr, m->w0, m->b0, m->w1, m->b1, m->ln_w, m->ln_b, x_out, (int)n_nodes};
-    const int g = grid_for((n_nodes + TM - 1) / TM, 1);
-    hipLaunchKernelGGL(mp_node_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
-    return check_launch("mgn_mp_node");
+    return launch_node(x, aggr, rowptr, m, nullptr, nullptr, x_out, nullptr, nullptr, n_nodes, stream, "mgn_mp_node");
+}
+
+extern "C" int mgn_mp_node_project(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* m,
+                                   const float* next_edge_w0, const float* next_edge_b0, float* x_out, float* ps,
+                                   float* pr, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(next_edge_w0 && next_edge_b0 && ps && pr, "mgn_mp_node_project");
+    return launch_node(x, aggr, rowptr, m, next_edge_w0, next_edge_b0, x_out, ps, pr, n_nodes, stream,
+                       "mgn_mp_node_project");
 }
 
 extern "C" int mgn_node_features(const float* world_pos, const float* mesh_pos, const float* phi,

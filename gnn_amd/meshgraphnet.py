@@ -110,21 +110,30 @@ class EdgeNodeMessagePassing(nn.Module):
                                   nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.LayerNorm(hidden_dim))
         self.__dict__["_topo"] = TopologyCache()
 
-    def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr, halo=None):
-        """In place on ``x`` [N,H] and ``e_csr`` [E,H] (receiver-major edge order).  With a
-        ``halo`` plan only the first ``halo.num_owned`` rows of ``x`` are owned; the sender
-        projections of the remaining (halo) rows arrive from their owners."""
+    def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr, halo=None, projected=False, next_block=None):
+        """In place on ``x`` [N,H] and ``e_csr`` [E,H] (receiver-major edge order).
+
+        ``projected``: ``ps``/``pr`` already hold this block's per-node projections (written by
+        the previous block's fused node kernel).  ``next_block``: the block that runs next; its
+        projections are then produced by this block's node kernel.  With a ``halo`` plan only
+        the first ``halo.num_owned`` rows of ``x`` are owned; the sender projections of the
+        remaining (halo) rows arrive from their owners."""
         ew, nw = self.edge_mlp.weights(), self.node_mlp.weights()
         n = x.shape[0] if halo is None else halo.num_owned
-        with ops.timed("mp_project"):
-            ops.mp_project(x[:n], self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps[:n], pr[:n])
+        if not projected:
+            with ops.timed("mp_project"):
+                ops.mp_project(x[:n], self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps[:n], pr[:n])
         if halo is not None:
             with ops.timed("halo_exchange"):
                 halo.exchange_rows(ps)
         with ops.timed("mp_edge"):
             ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
         with ops.timed("mp_node"):
-            ops.mp_node(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, x[:n])
+            if next_block is None:
+                ops.mp_node(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, x[:n])
+            else:
+                ops.mp_node_project(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, next_block.edge_mlp[0].weight.data,
+                                    next_block.edge_mlp[0].bias.data, x[:n], ps[:n], pr[:n])
 
     def forward(self, node_feat, edge_index, edge_feat):
         """node_feat [N,H], edge_index [2,E] (row 0 sender, row 1 receiver), edge_feat [E,H]
@@ -240,8 +249,10 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         ops.encode(ws.node_feat[:n_own], ms_n, self.node_encoder.weights(), ws.x[:n_own])
         ms_e = self.edge_features_normalizer.stats_for(ws.edge_feat, True, hook_e)
         ops.encode(ws.edge_feat, ms_e, self.edge_encoder.weights(), ws.e)
-        for proc in self.processors:
-            proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr, halo)
+        blocks = list(self.processors)
+        for i, proc in enumerate(blocks):
+            proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr, halo, projected=i > 0,
+                          next_block=blocks[i + 1] if i + 1 < len(blocks) else None)
         return ws, topo
 
     # ----------------------------------------------------------------- reference API

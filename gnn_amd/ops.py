@@ -153,6 +153,18 @@ def mp_node(x, aggr, rowptr, mlp: MlpWeights, x_out):
     _lib.check(rc, "mgn_mp_node")
 
 
+def mp_node_project(x, aggr, rowptr, mlp: MlpWeights, next_w0, next_b0, x_out, ps, pr):
+    n = x.shape[0]
+    if mlp.in_dim != 2 * H or mlp.out_dim != H:
+        raise RuntimeError("mp_node_project: node MLP must be 2H -> H -> H")
+    rc = _lib.lib().mgn_mp_node_project(
+        _dev(x, torch.float32, (n, H), "x"), _dev(aggr, torch.float32, (n, H), "aggr"),
+        _dev(rowptr, torch.int32, (n + 1,), "rowptr"), mlp.ref(), _dev(next_w0, torch.float32, (H, 3 * H), "next edge w0"),
+        _dev(next_b0, torch.float32, (H,), "next edge b0"), _dev(x_out, torch.float32, (n, H), "x_out"),
+        _dev(ps, torch.float32, (n, H), "ps"), _dev(pr, torch.float32, (n, H), "pr"), n, _stream())
+    _lib.check(rc, "mgn_mp_node_project")
+
+
 # --------------------------------------------------------------------------- device: features etc.
 def node_features(world_pos, mesh_pos, phi, swelling_phi, node_type, mat_param, feat):
     n = world_pos.shape[0]

@@ -87,9 +87,16 @@ int mgn_mp_edge(const float* e_in /*[E][H]*/, const float* ps, const float* pr,
 
 /* Node update (:116-118): x_out = LN(ReLU(W1 ReLU(W0 cat[x, aggr] + b0) + b1)) + x.
  * aggr rows of nodes with rowptr[n] == rowptr[n+1] are read as zero.
- * x_out must not alias x.                                                             */
+ * x_out may alias x.                                                                  */
 int mgn_mp_node(const float* x /*[N][H]*/, const float* aggr /*[N][H]*/, const int32_t* rowptr,
                 const mgn_mlp* node_mlp, float* x_out /*[N][H]*/, int64_t n_nodes, void* stream);
+
+/* The same node update fused with the NEXT layer's mgn_mp_project applied to x_out (saves one
+ * pass over the node latents per layer): ps/pr receive the projections of the updated latents
+ * through next_edge_w0 [H][3H] / next_edge_b0 [H].                                          */
+int mgn_mp_node_project(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* node_mlp,
+                        const float* next_edge_w0, const float* next_edge_b0,
+                        float* x_out, float* ps, float* pr, int64_t n_nodes, void* stream);
 
 /* ---- device side: features, normaliser, encoder, decoder --------------------------
  * _build_node_features (core/meshgraphnet.py:212-225): feat row =
