@@ -26,11 +26,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_EDGE_CANONICAL = 2 * (384 * 128 + 128 * 128)      # 131072: reference edge MLP
 FLOP_PER_NODE_CANONICAL = 2 * (256 * 128 + 128 * 128)      # 98304: reference node MLP
 FLOP_PER_EDGE_EDGE_KERNEL = 2 * (128 * 128 + 128 * 128)    # 65536: what mp_edge_kernel is responsible for
 BYTES_PER_EDGE_EDGE_KERNEL = 512 + 512 + 8                 # e in, e out, sender + receiver ids
+
+
+def pmc_traffic(kernel, edges):
+    """HBM bytes per launch of `kernel` from the committed counter pass (FETCH_SIZE and WRITE_SIZE are
+    collected in separate rocprofv3 --pmc runs, which a timed run cannot do itself); scales with the
+    edge count, None when no pass for this kernel is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    if rec.get("kernel") != kernel:
+        return None
+    return rec["traffic_bytes_per_edge"] * edges
 
 
 def parse():
@@ -164,11 +180,20 @@ def main():
         if "mp_edge" in kern_ms:
             t_edge = kern_ms["mp_edge"] * 1e-3
             ach = FLOP_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e12
-            out["roofline"] = {"kernel": "mp_edge_kernel", "bound": "mfma", "achieved": ach,
-                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": None, "avg_launch_ms": kern_ms["mp_edge"],
+            split = os.environ.get("MGN_MATMUL", "bf16x3") != "f32"
+            traffic = pmc_traffic("mp_edge3_kernel" if split else "mp_edge_kernel", e_local)
+            out["roofline"] = {"kernel": "mp_edge3_kernel" if split else "mp_edge_kernel", "bound": "mfma",
+                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                               "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC pass, see profiles/)",
+                               "avg_launch_ms": kern_ms["mp_edge"],
                                "flop_per_edge": FLOP_PER_EDGE_EDGE_KERNEL,
-                               "hbm_GBs_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e9}
+                               "hbm_GBs_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e9,
+                               "hbm_frac_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e9 / PEAK_HBM_GBS,
+                               "matrix_path": ("fp32 operands split exactly into 3 bf16 terms, 6 partial products on "
+                                               "v_mfma_f32_32x32x16_bf16, fp32 accumulate" if split
+                                               else "v_mfma_f32_32x32x2_f32"),
+                               "matrix_pipe_frac": (6 * ach / PEAK_BF16_MFMA_TFLOPS) if split else ach / PEAK_F32_MFMA_TFLOPS}
             # one MP step = everything the processor launches for one layer; the projection of
             # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
             n_layers = args.steps * args.mp_steps

@@ -21,6 +21,9 @@
 // order, so results do not depend on the launch geometry.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "mgn_internal.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -139,15 +142,6 @@ __device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, in
     return ln_finish(v, red, w, j, h, gamma_lds, beta_lds);
 }
 
-// Asynchronous copy of one 512-byte latent row from global memory into an LDS tile row
-// (global_load_lds: no destination registers).  Lanes 0..31 of the calling wave move 16 bytes
-// each; `lds_row` must be wave-uniform.  Completion: the issuing wave's vmcnt, then a barrier.
-__device__ __forceinline__ void dma_row(const float* grow, float* lds_row, int lane) {
-    if (lane < 32)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(grow + 4 * lane),
-                                         (__attribute__((address_space(3))) void*)lds_row, 16, 0, 0);
-}
-
 // store the accumulator (row j, features 32w..32w+31) into a [TM][H] LDS tile
 __device__ __forceinline__ void acc_to_tile(float* tile, f32x16 v, int w, int j, int h) {
 #pragma unroll
@@ -168,12 +162,6 @@ __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n,
     }
     return lo;
 }
-
-// Workgroup barrier that waits for this wave's LDS traffic only.  __syncthreads() would also
-// drain the vector-memory counter whenever an LDS-DMA is outstanding, stalling on global
-// stores and prefetches that nobody needs yet.
-__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void wait_vm_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ======================================================================== processor: edges
 // Two 4-wave workgroups per CU (one wave per SIMD each), every workgroup walking its own
@@ -313,6 +301,302 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
         }
         // the next iteration stages into the other X / rid buffer; Hs and red are rewritten
         // only after its barrier (A), which every thread reaches after finishing this pass
+    }
+}
+
+// Diagnostic build only (-DMGN_PHASE_STAMPS, see scripts/phase_stamps.py): cycle sums between
+// stamps of a kernel's main loop, taken by lane 0 of waves 0 and 2.  Never in the product build.
+#ifdef MGN_PHASE_STAMPS
+__device__ unsigned long long g_stamps[2][16];
+#define STAMP_DECL unsigned long long st_prev = 0, st_sum[16] = {0}; bool st_on = false;
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long now_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");       \
+        if (st_on) st_sum[i] += now_ - st_prev;                                           \
+        st_prev = now_; st_on = true;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#define STAMP_FLUSH(slot)                                                                 \
+    if ((threadIdx.x & 63) == 0 && (slot) >= 0)                                           \
+        for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stamps[slot][i_], st_sum[i_]);
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(slot)
+#endif
+
+// ======================================================================== split-bf16 matrix path
+// fp32 products on the bf16 matrix pipe.  Every fp32 operand is cut EXACTLY into three bf16
+// terms by truncation (8 + 8 + 8 significant bits: x = hi + mid + lo, no rounding anywhere),
+// and a product x*w is evaluated as the six partial products whose weight is >= 2^-16 of it:
+//   hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi        (dropped: mid*lo, lo*mid, lo*lo < 2^-23)
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  Unlike the fp32 MFMA, the
+// bf16 MFMA runs beside vector-ALU work of another wave on the same SIMD, and the six products
+// cost 6/16 of the fp32 matrix time.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int PK = H + 8;                          // bf16 per plane row: 256 B of data + 16 B pad
+constexpr int PLANE = TM * PK;                     // bf16 per plane of a 32-row tile
+
+// x = hi + mid + lo (exact); returns the three terms as fp32 bit patterns with 16 low zero bits
+__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    lo = __float_as_uint(r1 - __uint_as_float(mid));          // at most 8 significant bits are left
+}
+// two bf16 (upper halves of a and b) in one dword, a in the low half
+__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
+
+// four consecutive fp32 -> per plane two dwords (4 bf16)
+__device__ __forceinline__ void split_pack4(const f32x4 v, u32x2& ph, u32x2& pm, u32x2& pl) {
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
+    ph = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
+    pm = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
+    pl = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
+}
+
+// write 4 consecutive features of one tile row as three bf16 planes
+__device__ __forceinline__ void planes_store4(unsigned short* tile, int row, int k, const f32x4 v) {
+    u32x2 ph, pm, pl;
+    split_pack4(v, ph, pm, pl);
+    unsigned short* d = tile + row * PK + k;
+    *(u32x2*)(d) = ph; *(u32x2*)(d + PLANE) = pm; *(u32x2*)(d + 2 * PLANE) = pl;
+}
+
+// Register-resident weight planes of one 128-wide Linear for the 32 output features of a wave
+// (v_mfma_f32_32x32x16_bf16: lane (i = lane & 31, h = lane >> 5) feeds k = 16c + 8h + 0..7).
+struct WPlanes32 { u32x4 p[3][8]; };
+
+__device__ __forceinline__ void load_wplanes32(WPlanes32& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
+    const float* row = W + (size_t)feat * ldw + koff + 8 * h;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 lo4 = *(const f32x4*)(row + 16 * c), hi4 = *(const f32x4*)(row + 16 * c + 4);
+        u32x2 a[3], b[3];
+        split_pack4(lo4, a[0], a[1], a[2]);
+        split_pack4(hi4, b[0], b[1], b[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) w.p[p][c] = u32x4{a[p][0], a[p][1], b[p][0], b[p][1]};
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// acc[32 feats][32 rows] += W * planes^T over k-steps [C0, C1) of 16; `tile` = plane 0 of a
+// [3][TM][PK] bf16 image; lane (j = lane & 31, h = lane >> 5).  Smallest partial products first.
+template <int C0, int C1>
+__device__ __forceinline__ f32x16 wave_gemm3_32(const unsigned short* tile, const WPlanes32& w, int j, int h, f32x16 acc) {
+    const unsigned short* r = tile + j * PK + 8 * h;
+#pragma unroll
+    for (int c = C0; c < C1; ++c) {
+        const u32x4 xh = *(const u32x4*)(r + 16 * c), xm = *(const u32x4*)(r + PLANE + 16 * c),
+                    xl = *(const u32x4*)(r + 2 * PLANE + 16 * c);
+        acc = mfma32_bf16(w.p[2][c], xh, acc);   // lo * hi
+        acc = mfma32_bf16(w.p[0][c], xl, acc);   // hi * lo
+        acc = mfma32_bf16(w.p[1][c], xm, acc);   // mid * mid
+        acc = mfma32_bf16(w.p[1][c], xh, acc);   // mid * hi
+        acc = mfma32_bf16(w.p[0][c], xm, acc);   // hi * mid
+        acc = mfma32_bf16(w.p[0][c], xh, acc);   // hi * hi
+    }
+    return acc;
+}
+
+constexpr int NT3 = 512;
+
+// Edge update on the split-bf16 path: one 8-wave workgroup per CU, two roles that share every
+// SIMD pairwise (wave w and wave w + 4) and run as a three-deep software pipeline over 32-edge
+// tiles, so that one role's matrix phase always runs beside the other role's vector phase:
+//
+//   iteration i        role 0 (waves 0-3: first Linear)        role 1 (waves 4-7: second Linear)
+//   phase 1  ..bm..b1  product 1 of tile i (MFMA)              LayerNorm finish -> Es | store + scan, tile i-2
+//   phase 2  ..b2      ReLU, split -> Hp[i&1]; stage tile i+1  scan finish (i-2); product 2 of tile i-1 (MFMA), stats
+//
+// Wave w of a role owns output features [32w, 32w+32) of its Linear with the three bf16 weight
+// planes in registers (96 VGPRs).
+__global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * PLANE];      // staged e_in tile, 3 planes
+    __shared__ __attribute__((aligned(16))) unsigned short Hp[2][3 * PLANE];   // hidden tile, 3 planes, double buffered
+    __shared__ __attribute__((aligned(16))) float Es[tile_floats(H / 4)];      // pre-residual output tile (fp32)
+    __shared__ __attribute__((aligned(16))) float Gs[tile_floats(H / 4)];      // ps[sender] + pr[receiver] per tile row
+    __shared__ __attribute__((aligned(16))) float vec[3][H];                   // b1, ln_w, ln_b
+    __shared__ float red[16 * TM];
+    __shared__ float cout[H], tcarry[H];
+    __shared__ int srange[2];
+
+    const int t = threadIdx.x, lane = t & 63, role = t >> 8, w = (t >> 6) & 3, t1 = t & 255;
+    const int j = lane & 31, h = lane >> 5;
+
+    if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
+    if (t == 0) {
+        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+        const long long lo = (long long)rho * a.n_edges / nb, hi = (long long)(rho + 1) * a.n_edges / nb;
+        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
+        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
+    }
+    __syncthreads();
+    const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
+    if (e0 >= e1) return;
+    const int last = e1 - e0 - 1;                    // row offsets below are relative to e0 and clamped to [0, last]
+    const int ntiles = last / TM + 1;
+    const float* ein_g = a.e_in + (size_t)e0 * H;
+    float* eout_g = a.e_out + (size_t)e0 * H;
+    const int* snd_g = a.sender + e0;
+    const int* rcv_g = a.recv + e0;
+    const int srow = t1 >> 5, sq = t1 & 31;          // row-major map of a role's 256 threads: rows srow + 8*it, chunk sq
+
+    if (role == 0) {
+        // ------------------------------------------------------------------ role 0: first Linear
+        WPlanes32 wa;
+        load_wplanes32(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
+        f32x4 nx[4];
+        unsigned so[4], ro[4];                       // element offsets of the sender / receiver rows this thread gathers
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int r = min(srow + 8 * it, last);
+            nx[it] = *(const f32x4*)(ein_g + (unsigned)(r * H + 4 * sq));
+            so[it] = (unsigned)snd_g[r] * H + 4 * sq; ro[it] = (unsigned)rcv_g[r] * H + 4 * sq;
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) planes_store4(Xp, srow + 8 * it, 4 * sq, nx[it]);
+        __syncthreads();                                                     // b0: tile 0 staged
+        STAMP_DECL
+        for (int i = 0; i < ntiles + 2; ++i) {
+            STAMP(0);
+            const bool act = i < ntiles;
+            const int rel = i * TM;
+            f32x16 acc;
+            if (act) {
+                // this tile's per-node projections, gathered as whole 512-byte rows (thread = row, chunk)
+                // and summed into Gs; next tile's rows and ids
+                f32x4 ga[4], gb[4];
+#pragma unroll
+                for (int it = 0; it < 4; ++it) { ga[it] = *(const f32x4*)(a.ps + so[it]); gb[it] = *(const f32x4*)(a.pr + ro[it]); }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = min(rel + TM + srow + 8 * it, last);
+                    nx[it] = *(const f32x4*)(ein_g + (unsigned)(r * H + 4 * sq));
+                    so[it] = (unsigned)snd_g[r] * H + 4 * sq; ro[it] = (unsigned)rcv_g[r] * H + 4 * sq;
+                }
+                acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                acc = wave_gemm3_32<0, 4>(Xp, wa, j, h, acc);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) *(f32x4*)(Gs + toff(srow + 8 * it, sq, H / 4)) = ga[it] + gb[it];
+            }
+            STAMP(1);
+            __syncthreads();                                                 // bm
+            STAMP(2);
+            if (act) acc = wave_gemm3_32<4, 8>(Xp, wa, j, h, acc);
+            STAMP(3);
+            __syncthreads();                                                 // b1: every wave is done reading Xp; Gs complete
+            STAMP(4);
+            if (act) {
+                unsigned short* Hb = Hp[i & 1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 gg = *(const f32x4*)(Gs + toff(j, 8 * w + 2 * g + h, H / 4));
+                    f32x4 v;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[4 * g + k] + gg[k], 0.f);
+                    planes_store4(Hb, j, 32 * w + 8 * g + 4 * h, v);
+                }
+#pragma unroll
+                for (int it = 0; it < 4; ++it) planes_store4(Xp, srow + 8 * it, 4 * sq, nx[it]);   // tile i+1
+            }
+            STAMP(5);
+            __syncthreads();                                                 // b2
+        }
+        STAMP_FLUSH(w == 0 ? 0 : -1)
+    } else {
+        // ------------------------------------------------------------------ role 1: second Linear
+        WPlanes32 wb;
+        load_wplanes32(wb, a.w1, H, 0, 32 * w + j, h);
+        const int sc = t1 & (H - 1);
+        const int sg = __builtin_amdgcn_readfirstlane(t1 >> 7);     // scan group: rows 16*sg .. 16*sg+15
+        f32x16 acc;
+        f32x4 er[4];                                 // fp32 rows of the tile stored next (residual)
+        int ra = 0, rb = -1;                         // receiver of tile row (lane & 31) and of the row after it
+        float part = 0.f, cin = 0.f, xr[16];
+        unsigned mask = 0, gmask = 0;
+        __syncthreads();                                                     // b0
+        STAMP_DECL
+        for (int i = 0; i < ntiles + 2; ++i) {
+            STAMP(0);
+            const int k = i - 2;                     // tile in its LayerNorm / store stage
+            const int relk = k * TM, nvalid = min(TM, last + 1 - relk);
+            if (k >= 0) {
+                acc = ln_finish(acc, red, w, j, h, vec[1], vec[2]);
+                acc_to_tile(Es, acc, w, j, h);
+            }
+            STAMP(1);
+            __syncthreads();                                                 // bm
+            STAMP(2);
+            if (k >= 0) {
+                float* eo = eout_g + (unsigned)(relk * H);
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {     // residual + coalesced store
+                    const int row = srow + 8 * it;
+                    const f32x4 y = *(const f32x4*)(Es + toff(row, sq, H / 4));
+                    if (row < nvalid) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y + er[it];
+                }
+                // receiver-segmented sum: thread (column sc, group sg) scans rows 16sg .. 16sg+15 in
+                // order; xr[r] = sum of the rows since the last segment end before r
+                mask = (unsigned)__ballot(j < nvalid && ra != rb);          // bit r: row r ends its segment
+                gmask = (mask >> (16 * sg)) & 0xFFFFu;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[r] = Es[(16 * sg + r) * (H + 4) + sc];
+                part = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    part += xr[r];
+                    xr[r] = part;
+                    if ((gmask >> r) & 1u) part = 0.f;
+                }
+                if (sg == 0) cout[sc] = part;
+                cin = tcarry[sc];                    // open segment of the previous tile (rewritten after b1)
+            }
+            STAMP(3);
+            __syncthreads();                                                 // b1
+            STAMP(4);
+            if (k >= 0) {
+                // chain the two groups and the open segment of the previous tile, store the sums
+                if (sg == 1) { const float c0 = cout[sc]; cin = (mask & 0xFFFFu) ? c0 : cin + c0; }
+                bool open = true;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if ((gmask >> r) & 1u) {
+                        const int node = __builtin_amdgcn_readlane(ra, 16 * sg + r);
+                        a.aggr[(unsigned)(node * H + sc)] = open ? cin + xr[r] : xr[r];
+                        open = false;
+                    }
+                }
+                if (sg == 1) tcarry[sc] = gmask ? part : cin + part;         // read again after the next b1
+            }
+            STAMP(6);
+            if (i >= 1 && i <= ntiles) {             // tile i-1: second product + LayerNorm statistics
+                const int relm = (i - 1) * TM;
+#pragma unroll
+                for (int it = 0; it < 4; ++it)       // consumed one iteration later
+                    er[it] = *(const f32x4*)(ein_g + (unsigned)(min(relm + srow + 8 * it, last) * H + 4 * sq));
+                ra = rcv_g[min(relm + j, last)];
+                rb = (relm + j + 1 <= last) ? rcv_g[min(relm + j + 1, last)] : -1;
+                acc = acc_from_vec(vec[0], w, h);
+                acc = wave_gemm3_32<0, 8>(Hp[(i - 1) & 1], wb, j, h, acc);
+                acc = relu16(acc);
+                ln_local_stats(acc, red, w, j, h);
+            }
+            STAMP(5);
+            __syncthreads();                                                 // b2
+        }
+        STAMP_FLUSH(w == 0 ? 1 : -1)
     }
 }
 
@@ -751,11 +1035,34 @@ int check_launch(const char* what) {
     return 0;
 }
 
+// Edge-kernel matrix path: 1 = split-bf16 (three exact bf16 terms per fp32 operand, six partial
+// products, fp32 accumulation; the default), 0 = fp32 MFMA.  Both meet the same fp32 tolerance;
+// the environment variable MGN_MATMUL=f32|bf16x3 chooses explicitly.
+int matmul_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("MGN_MATMUL");
+        mode = (e && !strcmp(e, "f32")) ? 0 : 1;
+    }
+    return mode;
+}
+
 bool mlp_ok(const mgn_mlp* m, bool need_ln) {
     return m && m->w0 && m->b0 && m->w1 && m->b1 && (!need_ln || (m->ln_w && m->ln_b));
 }
 
 }  // namespace
+
+#ifdef MGN_PHASE_STAMPS
+extern "C" int mgn_debug_read_stamps(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 #define MGN_REQUIRE(cond, name)                                             \
     do { if (!(cond)) { mgn_set_error("%s: bad argument (%s)", name, #cond); return MGN_E_ARG; } } while (0)
@@ -781,8 +1088,13 @@ extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, 
     MGN_REQUIRE(n_nodes * (int64_t)H < (1ll << 31), "mgn_mp_edge");
     EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
                e_out, aggr, (int)n_edges, (int)n_nodes};
-    const int g = grid_for((n_edges + TM - 1) / TM, 2);
-    hipLaunchKernelGGL(mp_edge_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    if (matmul_mode() == 1) {
+        const int g = grid_for((n_edges + TM - 1) / TM, 1);
+        hipLaunchKernelGGL(mp_edge3_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);
+    } else {
+        const int g = grid_for((n_edges + TM - 1) / TM, 2);
+        hipLaunchKernelGGL(mp_edge_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    }
     return check_launch("mgn_mp_edge");
 }
 
