@@ -42,6 +42,15 @@ SIGNATURES = {
     "mgn_decode": (C.c_int, [_P, _MLP, _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_gather_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
     "mgn_scatter_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
+    "mgn_train_scratch_bytes": (_I64, []),
+    "mgn_train_linear_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _I64, _P]),
+    "mgn_train_ln_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgn_train_ln_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _I64, _P]),
+    "mgn_train_linear_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P, _P, _I32, _P, _P, _I64, _P]),
+    "mgn_segment_sum": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
+    "mgn_train_pad_features": (C.c_int, [_P, _I32, _P, _P, _I64, _P]),
+    "mgn_train_loss_fwd": (C.c_int, [_P, _P, _P, _I32, _I64, _P, _P, _P]),
+    "mgn_train_loss_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _P, _P]),
 }
 
 _lib = None

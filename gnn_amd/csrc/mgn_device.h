@@ -1,0 +1,174 @@
+// Device and host helpers shared by the kernel translation units of libmgn_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "mgn_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int H = MGN_H;    // latent width
+constexpr int TM = 32;      // rows per tile
+constexpr int NT = 256;     // threads per workgroup
+constexpr float LN_EPS = 1e-5f;
+
+// float offset of 16-byte chunk q of row `row` in a tile whose rows hold k4 chunks (+1 pad)
+__device__ __forceinline__ constexpr int tile_floats(int k4) { return TM * (4 * k4 + 4); }
+__device__ __forceinline__ int toff(int row, int q, int k4) { return row * (4 * k4 + 4) + 4 * q; }
+
+// Register-resident weight slice: for output feature `feat`, the k values this lane
+// feeds to the MFMAs of chunk c are W[feat][koff + 8c + 4h + 0..3].
+template <int KC>
+__device__ __forceinline__ void load_wfrag(f32x4 (&w)[KC], const float* __restrict__ W, int ldw, int koff,
+                                           int feat, int h, bool valid = true) {
+    const float* p = W + (size_t)feat * ldw + koff + 4 * h;
+#pragma unroll
+    for (int c = 0; c < KC; ++c) w[c] = valid ? *(const f32x4*)(p + 8 * c) : f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+// acc[feature][row] += W[feature][k] * tile[row][k] over k = 8*KC values starting at chunk qoff.
+// The LDS reads run two chunks ahead of the MFMAs that consume them.
+template <int KC>
+__device__ __forceinline__ f32x16 wave_gemm(const float* tile, int k4, int qoff, const f32x4 (&w)[KC],
+                                            int j, int h, f32x16 acc) {
+    const float* p = tile + toff(j, qoff + h, k4);
+    f32x4 a0 = *(const f32x4*)(p), a1 = *(const f32x4*)(p + 8);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // 2 LDS reads
+#pragma unroll
+    for (int c = 0; c < KC; c += 2) {
+        f32x4 n0 = a0, n1 = a1;
+        if (c + 2 < KC) {
+            n0 = *(const f32x4*)(p + 8 * (c + 2)); n1 = *(const f32x4*)(p + 8 * (c + 3));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // next two chunks first ...
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][0], a0[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][1], a0[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][2], a0[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c][3], a0[3], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][0], a1[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][1], a1[1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][2], a1[2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w[c + 1][3], a1[3], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);      // ... then the 8 MFMAs of this pair
+        a0 = n0; a1 = n1;
+    }
+    return acc;
+}
+
+__device__ __forceinline__ f32x16 acc_from_vec(const float* vec_lds, int w, int h) {
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 b = *(const f32x4*)(vec_lds + 32 * w + 8 * g + 4 * h);
+        acc[4 * g + 0] = b[0]; acc[4 * g + 1] = b[1]; acc[4 * g + 2] = b[2]; acc[4 * g + 3] = b[3];
+    }
+    return acc;
+}
+
+__device__ __forceinline__ f32x16 relu16(f32x16 v) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    return v;
+}
+
+// LayerNorm over the 128 features of every tile row.  Each lane holds 16 of a row's
+// features and forms their mean m and centred sum of squares M2 locally (two passes over
+// registers); the 8 (m, M2) pairs of a row (4 waves x 2 lane halves) meet in `red`, LDS
+// float[2][8][TM], and combine exactly as a pooled variance:
+//   mean = avg(m_k),  M2 = sum(M2_k) + 16 * sum((m_k - mean)^2),  var = M2 / 128 (biased).
+// Contains one workgroup barrier; after it every wave has finished reading whatever tile
+// fed the accumulators.
+__device__ __forceinline__ void ln_local_stats(const f32x16& v, float* red, int w, int j, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    const float m = s * (1.0f / 16.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = v[i] - m; q += d * d; }
+    red[(2 * w + h) * TM + j] = m;
+    red[8 * TM + (2 * w + h) * TM + j] = q;
+}
+
+__device__ __forceinline__ f32x16 ln_finish(f32x16 v, const float* red, int w, int j, int h,
+                                            const float* gamma_lds, const float* beta_lds) {
+    float mk[8], mean = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mk[k] = red[k * TM + j]; mean += mk[k]; m2 += red[8 * TM + k * TM + j]; }
+    mean *= 0.125f;
+    float between = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float d = mk[k] - mean; between += d * d; }
+    const float var = (m2 + 16.0f * between) * (1.0f / H);
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ga = *(const f32x4*)(gamma_lds + 32 * w + 8 * g + 4 * h);
+        const f32x4 be = *(const f32x4*)(beta_lds + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[4 * g + t] = (v[4 * g + t] - mean) * rstd * ga[t] + be[t];
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, int j, int h,
+                                                 const float* gamma_lds, const float* beta_lds) {
+    ln_local_stats(v, red, w, j, h);
+    __syncthreads();
+    return ln_finish(v, red, w, j, h, gamma_lds, beta_lds);
+}
+
+// store the accumulator (row j, features 32w..32w+31) into a [TM][H] LDS tile
+__device__ __forceinline__ void acc_to_tile(float* tile, f32x16 v, int w, int j, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *(f32x4*)(tile + toff(j, 8 * w + 2 * g + h, H / 4)) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+}
+
+// Blocks b and b + 8 share an XCD (and its L2); hand each XCD a contiguous run of ranges.
+__device__ __forceinline__ int range_of_block(int b, int nb) {
+    return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3);
+}
+
+__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, long long target) {
+    int lo = 0, hi = n;                       // first index with a[i] >= target, in [0, n]
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)a[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------------ host helpers
+inline int num_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cached[dev]) {
+        hipDeviceProp_t p;
+        cached[dev] = (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return cached[dev];
+}
+
+// number of workgroups for `ntiles` tiles at `per_cu` resident workgroups per CU;
+// a multiple of 8 whenever it exceeds 8 so the XCD mapping applies
+inline int grid_for(long long ntiles, int per_cu) {
+    long long g = (long long)num_cus() * per_cu;
+    if (ntiles < g) g = ntiles;
+    if (g > 8) g -= g % 8;
+    return (int)(g < 1 ? 1 : g);
+}
+
+inline int check_launch(const char* what) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { mgn_set_error("%s: %s", what, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
+}  // namespace
+
+#define MGN_REQUIRE(cond, name)                                             \
+    do { if (!(cond)) { mgn_set_error("%s: bad argument (%s)", name, #cond); return MGN_E_ARG; } } while (0)

@@ -1,0 +1,489 @@
+// Training side of libmgn_hip.so: forward-with-saved-activations and backward building
+// blocks of the MeshGraphNets MLPs for gfx950, fp32 throughout (fp32 MFMA for the products).
+//
+// Every 128-wide Linear of the model (inputs narrower than 128 are zero padded by the caller)
+// is evaluated by the same few row-tile kernels:
+//   train_linear_fwd   out = act(A Wa^T [+ B Wb^T] [+ bias] [+ P[idxP] + Q[idxQ]])
+//   train_ln_fwd       y = LayerNorm(v) [, y + res]
+//   train_ln_bwd       grad wrt LayerNorm input (optionally through a preceding ReLU), dgamma, dbeta
+//   train_linear_bwd   dW = G^T A, db = colsum(G), GA = (G W) [* (mask > 0)] [+ res]
+//   segment_sum        out[n] = sum of rows rowptr[n] .. rowptr[n+1] (optionally through an index list)
+// Weight and bias gradients are summed per workgroup in registers, written to a scratch
+// buffer and reduced by a second kernel in block order, so they are deterministic.
+#include <hip/hip_runtime.h>
+
+#include "mgn_device.h"
+
+namespace {
+
+constexpr int PARTIAL_W = H * H;            // floats of one workgroup's weight-gradient partial
+constexpr int PARTIAL = PARTIAL_W + H;      // + bias-gradient partial
+constexpr int TRAIN_BLOCKS_MAX = 1024;
+
+// Transposed register-resident weight slice: for output column `col` (an input feature of the
+// Linear), the contraction runs over the Linear's output features f = 8c + 4h + 0..3.
+__device__ __forceinline__ void load_wfrag_t(f32x4 (&w)[16], const float* __restrict__ W, int ldw, int col, int h) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const float* p = W + (size_t)(8 * c + 4 * h) * ldw + col;
+        w[c] = f32x4{p[0], p[ldw], p[2 * (size_t)ldw], p[3 * (size_t)ldw]};
+    }
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+}
+
+// contiguous tile range of this workgroup
+__device__ __forceinline__ void tile_range(long long rows, int& t0, int& t1) {
+    const int ntiles = (int)((rows + TM - 1) / TM);
+    const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+    t0 = (int)((long long)rho * ntiles / nb);
+    t1 = (int)((long long)(rho + 1) * ntiles / nb);
+}
+
+// ------------------------------------------------------------------------ linear forward
+struct LinFwdArgs {
+    const float* A; const float* B; const float* W; int ldw; int koff_a; int koff_b;
+    const float* bias; const float* P; const int* idxP; const float* Q; const int* idxQ;
+    int relu; float* out; long long rows;
+};
+
+template <bool TWO>
+__global__ __launch_bounds__(NT, 2) void train_linear_fwd_kernel(LinFwdArgs a) {
+    constexpr int K4 = TWO ? H / 2 : H / 4;
+    __shared__ __attribute__((aligned(16))) float X[tile_floats(K4)];
+    __shared__ __attribute__((aligned(16))) float O[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float vec[H];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    f32x4 wa[16], wb[TWO ? 16 : 1];
+    load_wfrag<16>(wa, a.W, a.ldw, a.koff_a, 32 * w + j, h);
+    if constexpr (TWO) load_wfrag<16>(wb, a.W, a.ldw, a.koff_b, 32 * w + j, h);
+    if (t < H) vec[t] = a.bias ? a.bias[t] : 0.f;
+    int t0, t1;
+    tile_range(a.rows, t0, t1);
+    const int srow = t >> 5, sq = t & 31;
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+        const long long base = (long long)tile * TM;
+        const int nvalid = (int)min((long long)TM, a.rows - base);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            const long long n = min(base + row, a.rows - 1);
+            *(f32x4*)(X + toff(row, sq, K4)) = *(const f32x4*)(a.A + n * H + 4 * sq);
+            if constexpr (TWO) *(f32x4*)(X + toff(row, 32 + sq, K4)) = *(const f32x4*)(a.B + n * H + 4 * sq);
+        }
+        __syncthreads();
+        f32x16 acc = acc_from_vec(vec, w, h);
+        acc = wave_gemm<16>(X, K4, 0, wa, j, h, acc);
+        if constexpr (TWO) acc = wave_gemm<16>(X, K4, 32, wb, j, h, acc);
+        if (a.P) {                                   // per-row gathered addends, accumulator layout
+            const long long n = min(base + j, a.rows - 1);
+            const size_t ip = (size_t)a.idxP[n] * H, iq = (size_t)a.idxQ[n] * H;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 p = *(const f32x4*)(a.P + ip + 32 * w + 8 * g + 4 * h);
+                const f32x4 q = *(const f32x4*)(a.Q + iq + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[4 * g + k] += p[k] + q[k];
+            }
+        }
+        if (a.relu) acc = relu16(acc);
+        acc_to_tile(O, acc, w, j, h);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            if (row < nvalid) *(f32x4*)(a.out + (base + row) * H + 4 * sq) = *(const f32x4*)(O + toff(row, sq, H / 4));
+        }
+        // X is restaged at the top of the next pass: every wave has finished its products before
+        // the barrier above; O is rewritten only after the next pass's first barrier
+    }
+}
+
+// ------------------------------------------------------------------------ LayerNorm forward
+// 32 lanes per row, 16 bytes per lane; statistics as torch computes them (mean, then the mean
+// of squared deviations).
+__device__ __forceinline__ float row_sum32(float v) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) v += __shfl_xor(v, m, 32);
+    return v;
+}
+
+__device__ __forceinline__ void row_stats(const f32x4 v, float& mean, float& rstd) {
+    mean = row_sum32(v[0] + v[1] + v[2] + v[3]) * (1.0f / H);
+    const f32x4 d = v - mean;
+    const float var = row_sum32(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]) * (1.0f / H);
+    rstd = 1.0f / sqrtf(var + LN_EPS);
+}
+
+__global__ __launch_bounds__(NT) void train_ln_fwd_kernel(const float* __restrict__ v, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* res,
+                                                          float* y, float* yres, long long rows) {
+    const int sq = threadIdx.x & 31;
+    const f32x4 ga = *(const f32x4*)(gamma + 4 * sq), be = *(const f32x4*)(beta + 4 * sq);
+    for (long long r = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); r < rows; r += (long long)gridDim.x * 8) {
+        const f32x4 x = *(const f32x4*)(v + r * H + 4 * sq);
+        float mean, rstd;
+        row_stats(x, mean, rstd);
+        const f32x4 o = (x - mean) * rstd * ga + be;
+        if (y) *(f32x4*)(y + r * H + 4 * sq) = o;
+        if (yres) *(f32x4*)(yres + r * H + 4 * sq) = o + *(const f32x4*)(res + r * H + 4 * sq);
+    }
+}
+
+// ------------------------------------------------------------------------ LayerNorm backward
+// gy = G[r] (+ Gg[idx[r]]);  gv = rstd * (gy*gamma - mean(gy*gamma) - vhat * mean(gy*gamma*vhat));
+// with relu_mask the gradient continues through the ReLU that produced v (v > 0).
+// partial[block][0..127] = sum gy * vhat (dgamma), [128..255] = sum gy (dbeta).
+__global__ __launch_bounds__(NT) void train_ln_bwd_kernel(const float* __restrict__ G, const float* __restrict__ Gg,
+                                                          const int* __restrict__ idx, const float* __restrict__ v,
+                                                          const float* __restrict__ gamma, int relu_mask,
+                                                          float* __restrict__ gpre, float* __restrict__ partial,
+                                                          long long rows) {
+    __shared__ __attribute__((aligned(16))) float sh[8][2 * H];
+    const int sq = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const f32x4 ga = *(const f32x4*)(gamma + 4 * sq);
+    f32x4 dg = {0.f, 0.f, 0.f, 0.f}, db = {0.f, 0.f, 0.f, 0.f};
+    // contiguous row range per workgroup, rows dealt to the 8 row groups in turn
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    for (long long r = r0 + grp; r < r1; r += 8) {
+        f32x4 gy = {0.f, 0.f, 0.f, 0.f};
+        if (G) gy = *(const f32x4*)(G + r * H + 4 * sq);
+        if (Gg) gy += *(const f32x4*)(Gg + (size_t)idx[r] * H + 4 * sq);
+        const f32x4 x = *(const f32x4*)(v + r * H + 4 * sq);
+        float mean, rstd;
+        row_stats(x, mean, rstd);
+        const f32x4 xh = (x - mean) * rstd;
+        dg += gy * xh; db += gy;
+        const f32x4 gh = gy * ga;
+        const float m1 = row_sum32(gh[0] + gh[1] + gh[2] + gh[3]) * (1.0f / H);
+        const float m2 = row_sum32(gh[0] * xh[0] + gh[1] * xh[1] + gh[2] * xh[2] + gh[3] * xh[3]) * (1.0f / H);
+        f32x4 gv = (gh - m1 - xh * m2) * rstd;
+        if (relu_mask) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) gv[k] = x[k] > 0.f ? gv[k] : 0.f;
+        }
+        *(f32x4*)(gpre + r * H + 4 * sq) = gv;
+    }
+    *(f32x4*)(&sh[grp][4 * sq]) = dg;
+    *(f32x4*)(&sh[grp][H + 4 * sq]) = db;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) s += sh[g][threadIdx.x];
+    partial[(size_t)blockIdx.x * (2 * H) + threadIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------ linear backward
+struct LinBwdArgs {
+    const float* G; const float* A; const float* W; int ldw; int koff;
+    const float* mask; const float* res; float* GA; float* partial; long long rows;
+};
+
+template <bool DO_GA, bool DO_DW>
+__global__ __launch_bounds__(NT, 2) void train_linear_bwd_kernel(LinBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float Gt[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) float At[DO_DW ? tile_floats(H / 4) : 4];
+    __shared__ __attribute__((aligned(16))) float Ot[DO_GA ? tile_floats(H / 4) : 4];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    f32x4 wt[DO_GA ? 16 : 1];
+    if constexpr (DO_GA) load_wfrag_t(wt, a.W, a.ldw, a.koff + 32 * w + j, h);
+    f32x16 dw[DO_DW ? 4 : 1];
+#pragma unroll
+    for (int kb = 0; kb < (DO_DW ? 4 : 1); ++kb) dw[kb] = zero16();
+    float dbias = 0.f;
+    int t0, t1;
+    tile_range(a.rows, t0, t1);
+    const int srow = t >> 5, sq = t & 31;
+    constexpr int LD = H + 4;                      // tile row stride in floats
+    for (int tile = t0; tile < t1; ++tile) {
+        const long long base = (long long)tile * TM;
+        const int nvalid = (int)min((long long)TM, a.rows - base);
+        __syncthreads();                           // previous pass done with Gt / At / Ot
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            const bool ok = row < nvalid;          // rows past the end contribute zeros to the sums
+            const long long n = min(base + row, a.rows - 1);
+            const f32x4 g = *(const f32x4*)(a.G + n * H + 4 * sq);
+            *(f32x4*)(Gt + toff(row, sq, H / 4)) = ok ? g : f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (DO_DW) *(f32x4*)(At + toff(row, sq, H / 4)) = *(const f32x4*)(a.A + n * H + 4 * sq);
+        }
+        __syncthreads();
+        if constexpr (DO_GA) {
+            f32x16 acc = zero16();
+            acc = wave_gemm<16>(Gt, H / 4, 0, wt, j, h, acc);
+            acc_to_tile(Ot, acc, w, j, h);
+        }
+        if constexpr (DO_DW) {
+#pragma unroll
+            for (int s = 0; s < TM / 2; ++s) {
+                const float gval = Gt[(2 * s + h) * LD + 32 * w + j];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+                    dw[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(gval, At[(2 * s + h) * LD + 32 * kb + j], dw[kb], 0, 0, 0);
+            }
+            if (t < H) {
+#pragma unroll 8
+                for (int r = 0; r < TM; ++r) dbias += Gt[r * LD + t];
+            }
+        }
+        if constexpr (DO_GA) {
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
+                if (row < nvalid) {
+                    const size_t o = (size_t)(base + row) * H + 4 * sq;
+                    f32x4 val = *(const f32x4*)(Ot + toff(row, sq, H / 4));
+                    if (a.mask) {
+                        const f32x4 m = *(const f32x4*)(a.mask + o);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] = m[k] > 0.f ? val[k] : 0.f;
+                    }
+                    if (a.res) val += *(const f32x4*)(a.res + o);
+                    *(f32x4*)(a.GA + o) = val;
+                }
+            }
+        }
+    }
+    if constexpr (DO_DW) {
+        float* p = a.partial + (size_t)blockIdx.x * PARTIAL;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int f = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                p[f * H + 32 * kb + j] = dw[kb][reg];
+            }
+        if (t < H) p[PARTIAL_W + t] = dbias;
+    }
+}
+
+// out[(i / width) * ld + (i % width)] = sum over blocks of partial[b * stride + offset + i], in block order
+__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, int offset,
+                                       int count, int width, int ld, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * stride + offset + i];
+    out[(size_t)(i / width) * ld + (i % width)] = s;
+}
+
+// ------------------------------------------------------------------------ segmented row sums
+__global__ __launch_bounds__(NT) void segment_sum_kernel(const float* __restrict__ src, const int* __restrict__ rowptr,
+                                                         const int* __restrict__ order, float* __restrict__ out,
+                                                         long long n_seg) {
+    const int sq = threadIdx.x & 31;
+    for (long long n = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); n < n_seg; n += (long long)gridDim.x * 8) {
+        const int k0 = rowptr[n], k1 = rowptr[n + 1];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = k0; k < k1; ++k) {
+            const size_t row = order ? (size_t)order[k] : (size_t)k;
+            s += *(const f32x4*)(src + row * H + 4 * sq);
+        }
+        *(f32x4*)(out + n * H + 4 * sq) = s;
+    }
+}
+
+// ------------------------------------------------------------------------ features, loss
+__global__ void pad_features_kernel(const float* __restrict__ feat, const float* __restrict__ mean_std,
+                                    float* __restrict__ out, long long rows, int F) {
+    const long long total = rows * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long r = i / H; const int k = (int)(i - r * H);
+        float v = 0.f;
+        if (k < F) {
+            v = feat[r * F + k];
+            if (mean_std) v = (v - mean_std[k]) / mean_std[F + k];
+        }
+        out[i] = v;
+    }
+}
+
+// per component c: sum over t and over nodes without the Dirichlet flag of column c + 1 of
+// (decoded[n][3t + c] * (t + 1) - target[t][n][c])^2; partial[block][c] in double
+__global__ __launch_bounds__(NT) void loss_fwd_kernel(const float* __restrict__ dec, const float* __restrict__ tgt,
+                                                      const float* __restrict__ node_type, int T, long long n_nodes,
+                                                      double* __restrict__ partial) {
+    __shared__ double sh[NT];
+    double s[3] = {0.0, 0.0, 0.0};
+    const long long per = (n_nodes + gridDim.x - 1) / gridDim.x;
+    const long long n0 = (long long)blockIdx.x * per, n1 = min(n_nodes, n0 + per);
+    for (long long n = n0 + threadIdx.x; n < n1; n += NT)
+        for (int c = 0; c < 3; ++c) {
+            if (node_type[n * 5 + c + 1] == 1.0f) continue;
+            for (int tt = 0; tt < T; ++tt) {
+                const float d = dec[n * H + 3 * tt + c] * (float)(tt + 1) - tgt[((size_t)tt * n_nodes + n) * 3 + c];
+                s[c] += (double)(d * d);
+            }
+        }
+    for (int c = 0; c < 3; ++c) {
+        sh[threadIdx.x] = s[c];
+        __syncthreads();
+        for (int m = NT / 2; m >= 1; m >>= 1) {
+            if (threadIdx.x < m) sh[threadIdx.x] += sh[threadIdx.x + m];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 3 + c] = sh[0];
+        __syncthreads();
+    }
+}
+
+__global__ void loss_final_kernel(const double* __restrict__ partial, int nblocks, int T, float* __restrict__ out3) {
+    const int c = threadIdx.x;
+    if (c >= 3) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 3 + c];
+    out3[c] = (float)(s / (double)T);
+}
+
+// gradient of sum_c gsc[c] * loss_c with respect to the padded decoder output [N,128]
+__global__ void loss_bwd_kernel(const float* __restrict__ dec, const float* __restrict__ tgt,
+                                const float* __restrict__ node_type, const float* __restrict__ gsc, int T,
+                                long long n_nodes, float* __restrict__ gdec) {
+    const long long total = n_nodes * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long n = i / H; const int k = (int)(i - n * H);
+        float g = 0.f;
+        if (k < 3 * T) {
+            const int tt = k / 3, c = k - 3 * tt;
+            if (node_type[n * 5 + c + 1] != 1.0f) {
+                const float sc = (float)(tt + 1);
+                const float d = dec[i] * sc - tgt[((size_t)tt * n_nodes + n) * 3 + c];
+                g = gsc[c] * (2.0f / (float)T) * d * sc;
+            }
+        }
+        gdec[i] = g;
+    }
+}
+
+int train_grid(long long rows, int per_cu) { return grid_for((rows + TM - 1) / TM, per_cu); }
+
+int stream_grid(long long items, int per_block) {
+    long long g = (items + per_block - 1) / per_block;
+    const long long cap = (long long)num_cus() * 8;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int64_t mgn_train_scratch_bytes(void) {
+    return (int64_t)TRAIN_BLOCKS_MAX * PARTIAL * (int64_t)sizeof(float);
+}
+
+extern "C" int mgn_train_linear_fwd(const float* A, const float* B, const float* W, int32_t ldw, int32_t koff_a,
+                                    int32_t koff_b, const float* bias, const float* P, const int32_t* idxP,
+                                    const float* Q, const int32_t* idxQ, int32_t relu, float* out, int64_t rows,
+                                    void* stream) {
+    MGN_REQUIRE(rows >= 0 && rows < (1ll << 31), "mgn_train_linear_fwd");
+    if (rows == 0) return 0;
+    MGN_REQUIRE(A && W && out && ldw >= H && koff_a >= 0 && koff_a + H <= ldw, "mgn_train_linear_fwd");
+    MGN_REQUIRE(!B || (koff_b >= 0 && koff_b + H <= ldw), "mgn_train_linear_fwd");
+    MGN_REQUIRE((!P && !Q) || (P && Q && idxP && idxQ), "mgn_train_linear_fwd");
+    MGN_REQUIRE(ldw % 4 == 0 && koff_a % 4 == 0 && koff_b % 4 == 0, "mgn_train_linear_fwd");
+    LinFwdArgs a{A, B, W, ldw, koff_a, koff_b, bias, P, idxP, Q, idxQ, relu, out, rows};
+    const int g = train_grid(rows, 2);
+    if (B) hipLaunchKernelGGL((train_linear_fwd_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((train_linear_fwd_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_train_linear_fwd");
+}
+
+extern "C" int mgn_train_ln_fwd(const float* v, const float* gamma, const float* beta, const float* res, float* y,
+                                float* yres, int64_t rows, void* stream) {
+    MGN_REQUIRE(rows >= 0, "mgn_train_ln_fwd");
+    if (rows == 0) return 0;
+    MGN_REQUIRE(v && gamma && beta && (y || yres) && (!yres || res), "mgn_train_ln_fwd");
+    hipLaunchKernelGGL(train_ln_fwd_kernel, dim3(stream_grid(rows, 8)), dim3(NT), 0, (hipStream_t)stream, v, gamma,
+                       beta, res, y, yres, (long long)rows);
+    return check_launch("mgn_train_ln_fwd");
+}
+
+extern "C" int mgn_train_ln_bwd(const float* G, const float* Gg, const int32_t* idx, const float* v,
+                                const float* gamma, int32_t relu_mask, float* gpre, float* dgamma, float* dbeta,
+                                void* scratch, int64_t rows, void* stream) {
+    MGN_REQUIRE(rows > 0, "mgn_train_ln_bwd");
+    MGN_REQUIRE((G || Gg) && (!Gg || idx) && v && gamma && gpre && dgamma && dbeta && scratch, "mgn_train_ln_bwd");
+    int g = stream_grid(rows, 64);
+    if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX;
+    hipLaunchKernelGGL(train_ln_bwd_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, G, Gg, idx, v, gamma,
+                       relu_mask, gpre, (float*)scratch, (long long)rows);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(H), 0, (hipStream_t)stream, (const float*)scratch, g,
+                       2 * H, 0, H, H, H, dgamma);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(H), 0, (hipStream_t)stream, (const float*)scratch, g,
+                       2 * H, H, H, H, H, dbeta);
+    return check_launch("mgn_train_ln_bwd");
+}
+
+extern "C" int mgn_train_linear_bwd(const float* G, const float* A, const float* W, int32_t ldw, int32_t koff,
+                                    const float* mask, const float* res, float* GA, float* dW, int32_t lddw,
+                                    float* db, void* scratch, int64_t rows, void* stream) {
+    MGN_REQUIRE(rows > 0 && rows < (1ll << 31), "mgn_train_linear_bwd");
+    MGN_REQUIRE(G && (GA || dW), "mgn_train_linear_bwd");
+    MGN_REQUIRE(!GA || (W && ldw >= H && koff >= 0 && koff + H <= ldw), "mgn_train_linear_bwd");
+    MGN_REQUIRE(!dW || (A && scratch && lddw >= H), "mgn_train_linear_bwd");
+    MGN_REQUIRE(!db || dW, "mgn_train_linear_bwd");
+    LinBwdArgs a{G, A, W, ldw, koff, mask, res, GA, (float*)scratch, rows};
+    int g = train_grid(rows, 2);
+    if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX - TRAIN_BLOCKS_MAX % 8;
+    hipStream_t s = (hipStream_t)stream;
+    if (GA && dW) hipLaunchKernelGGL((train_linear_bwd_kernel<true, true>), dim3(g), dim3(NT), 0, s, a);
+    else if (GA) hipLaunchKernelGGL((train_linear_bwd_kernel<true, false>), dim3(g), dim3(NT), 0, s, a);
+    else hipLaunchKernelGGL((train_linear_bwd_kernel<false, true>), dim3(g), dim3(NT), 0, s, a);
+    if (dW) {
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(PARTIAL_W / NT), dim3(NT), 0, s, (const float*)scratch, g,
+                           PARTIAL, 0, PARTIAL_W, H, lddw, dW);
+        if (db)
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(H), 0, s, (const float*)scratch, g, PARTIAL,
+                               PARTIAL_W, H, H, H, db);
+    }
+    return check_launch("mgn_train_linear_bwd");
+}
+
+extern "C" int mgn_segment_sum(const float* src, const int32_t* rowptr, const int32_t* order, float* out,
+                               int64_t n_segments, void* stream) {
+    MGN_REQUIRE(n_segments >= 0, "mgn_segment_sum");
+    if (n_segments == 0) return 0;
+    MGN_REQUIRE(src && rowptr && out, "mgn_segment_sum");
+    hipLaunchKernelGGL(segment_sum_kernel, dim3(stream_grid(n_segments, 8)), dim3(NT), 0, (hipStream_t)stream, src,
+                       rowptr, order, out, (long long)n_segments);
+    return check_launch("mgn_segment_sum");
+}
+
+extern "C" int mgn_train_pad_features(const float* feat, int32_t n_feat, const float* mean_std, float* out,
+                                      int64_t rows, void* stream) {
+    MGN_REQUIRE(rows >= 0 && n_feat >= 1 && n_feat <= H, "mgn_train_pad_features");
+    if (rows == 0) return 0;
+    MGN_REQUIRE(feat && out, "mgn_train_pad_features");
+    hipLaunchKernelGGL(pad_features_kernel, dim3(stream_grid(rows * H, NT * 4)), dim3(NT), 0, (hipStream_t)stream, feat,
+                       mean_std, out, (long long)rows, n_feat);
+    return check_launch("mgn_train_pad_features");
+}
+
+extern "C" int mgn_train_loss_fwd(const float* decoded, const float* target_norm, const float* node_type,
+                                  int32_t time_dim, int64_t n_nodes, float* loss3, void* scratch, void* stream) {
+    MGN_REQUIRE(n_nodes > 0 && time_dim >= 1 && 3 * time_dim <= MGN_MAX_DEC_OUT, "mgn_train_loss_fwd");
+    MGN_REQUIRE(decoded && target_norm && node_type && loss3 && scratch, "mgn_train_loss_fwd");
+    int g = stream_grid(n_nodes, NT * 4);
+    if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX;
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, decoded, target_norm, node_type,
+                       time_dim, (long long)n_nodes, (double*)scratch);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const double*)scratch, g, time_dim,
+                       loss3);
+    return check_launch("mgn_train_loss_fwd");
+}
+
+extern "C" int mgn_train_loss_bwd(const float* decoded, const float* target_norm, const float* node_type,
+                                  const float* grad3, int32_t time_dim, int64_t n_nodes, float* gdecoded, void* stream) {
+    MGN_REQUIRE(n_nodes > 0 && time_dim >= 1 && 3 * time_dim <= MGN_MAX_DEC_OUT, "mgn_train_loss_bwd");
+    MGN_REQUIRE(decoded && target_norm && node_type && grad3 && gdecoded, "mgn_train_loss_bwd");
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(stream_grid(n_nodes * H, NT * 4)), dim3(NT), 0, (hipStream_t)stream, decoded,
+                       target_norm, node_type, grad3, time_dim, (long long)n_nodes, gdecoded);
+    return check_launch("mgn_train_loss_bwd");
+}

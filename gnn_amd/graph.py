@@ -80,6 +80,20 @@ class Topology:
         self.recv = torch.from_numpy(np.ascontiguousarray(cr)).to(self.device)
         self.perm = torch.from_numpy(np.ascontiguousarray(perm)).to(self.device)
         self.max_in_degree = int(np.diff(rowptr).max()) if num_nodes > 0 else 0
+        self._sender_view = None
+
+    def sender_view(self):
+        """(sender_rowptr int32 [N+1], sender_order int32 [E]): the CSR edges sent by node n are
+        ``sender_order[sender_rowptr[n] : sender_rowptr[n+1]]`` in ascending CSR position.  Used
+        by the backward pass to sum edge gradients per sender without atomics."""
+        if self._sender_view is None:
+            snd = self.sender.cpu().numpy()
+            order = np.argsort(snd, kind="stable").astype(np.int32)
+            rowptr = np.zeros(self.num_nodes + 1, dtype=np.int64)
+            np.cumsum(np.bincount(snd, minlength=self.num_nodes), out=rowptr[1:])
+            self._sender_view = (torch.from_numpy(rowptr.astype(np.int32)).to(self.device),
+                                 torch.from_numpy(order).to(self.device))
+        return self._sender_view
 
 
 class TopologyCache:

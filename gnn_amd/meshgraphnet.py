@@ -283,22 +283,19 @@ class EncodeProcessDecodeMultiScale(nn.Module):
 
     def loss(self, graph):
         """Masked squared error between the normalised target delta and the prediction
-        (core/meshgraphnet.py:285-304).  The output normaliser accumulates first (:290)."""
+        (core/meshgraphnet.py:285-304): returns (total, ux, uy, phi).  The output normaliser
+        accumulates first (:290).  With gradients enabled the result carries the backward pass
+        of the HIP training kernels, so ``loss.backward()`` fills ``.grad`` of every parameter
+        as run_train_multiscale.py:139-141 expects."""
+        from . import training
         target = self._f32(graph["target"])
         cur = torch.cat([self._f32(graph["world_pos"]), self._f32(graph["phi"])], dim=-1)
-        tgt = self.output_normalizer(target - cur)
+        tgt = self.output_normalizer(target - cur).contiguous()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError(
-                "loss: the backward kernels are not built yet; call under torch.no_grad() for the forward value")
-        pred = self.forward(graph)
-        err = (pred - tgt) ** 2
-        nt = self._f32(graph["node_type"])
-        parts = []
-        for k in range(3):
-            keep = ~(nt[:, k + 1] == 1)
-            sl = slice(k, k + 1) if k < 2 else slice(2, None)
-            parts.append(torch.mean(torch.sum(torch.sum(err[:, keep, sl], dim=2), dim=1)))
-        return parts[0] + parts[1] + parts[2], parts[0], parts[1], parts[2]
+            comps = training.loss_components(self, graph, tgt)
+        else:
+            comps, _ = training.forward_saving(self, graph, tgt)
+        return comps[0] + comps[1] + comps[2], comps[0], comps[1], comps[2]
 
     def save_model(self, path):
         """Checkpoint layout of the reference (core/meshgraphnet.py:318-324)."""

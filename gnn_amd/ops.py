@@ -254,3 +254,128 @@ def scatter_rows(src, idx, dst):
     rc = _lib.lib().mgn_scatter_rows(_dev(src, torch.float32, (m, wd), "src"), _dev(idx, torch.int64, (m,), "idx"),
                                      _dev(dst, torch.float32, (None, wd), "dst"), m, wd, _stream())
     _lib.check(rc, "mgn_scatter_rows")
+
+
+# --------------------------------------------------------------------------- device: training blocks
+def train_scratch_bytes() -> int:
+    return int(_lib.lib().mgn_train_scratch_bytes())
+
+
+def _rows128(t, name, rows=None):
+    return _dev(t, torch.float32, (rows, H), name)
+
+
+def _wblock(w, koff, name):
+    """[128, ldw] fp32 weight whose columns koff .. koff+127 are used."""
+    p = _dev(w, torch.float32, (H, None), name)
+    if w.shape[1] % 4 or koff % 4 or koff < 0 or koff + H > w.shape[1]:
+        raise RuntimeError(f"{name}: column block {koff}..{koff + H} does not fit a [{H},{w.shape[1]}] weight")
+    return p
+
+
+def train_linear_fwd(a, w, koff_a, out, b=None, koff_b=0, bias=None, p=None, idx_p=None, q=None, idx_q=None,
+                     relu=False):
+    rows = a.shape[0]
+    if (p is None) != (q is None) or (p is not None and (idx_p is None or idx_q is None)):
+        raise RuntimeError("train_linear_fwd: the gathered addends come as (p, idx_p, q, idx_q) or not at all")
+    if b is not None and koff_b + H > w.shape[1]:
+        raise RuntimeError("train_linear_fwd: second column block out of range")
+    rc = _lib.lib().mgn_train_linear_fwd(
+        _rows128(a, "A"), _opt(b, torch.float32, (rows, H), "B"), _wblock(w, koff_a, "W"), w.shape[1], koff_a, koff_b,
+        _opt(bias, torch.float32, (H,), "bias"), _opt(p, torch.float32, (None, H), "P"),
+        _opt(idx_p, torch.int32, (rows,), "idxP"), _opt(q, torch.float32, (None, H), "Q"),
+        _opt(idx_q, torch.int32, (rows,), "idxQ"), int(bool(relu)), _rows128(out, "out", rows), rows, _stream())
+    _lib.check(rc, "mgn_train_linear_fwd")
+
+
+def train_ln_fwd(v, gamma, beta, y=None, res=None, yres=None):
+    rows = v.shape[0]
+    if (y is None and yres is None) or ((yres is None) != (res is None)):
+        raise RuntimeError("train_ln_fwd: give y and/or (res, yres)")
+    rc = _lib.lib().mgn_train_ln_fwd(_rows128(v, "v"), _dev(gamma, torch.float32, (H,), "gamma"),
+                                     _dev(beta, torch.float32, (H,), "beta"), _opt(res, torch.float32, (rows, H), "res"),
+                                     _opt(y, torch.float32, (rows, H), "y"), _opt(yres, torch.float32, (rows, H), "yres"),
+                                     rows, _stream())
+    _lib.check(rc, "mgn_train_ln_fwd")
+
+
+def _scratch(scratch):
+    p = _dev(scratch, torch.uint8, None, "scratch")
+    if scratch.numel() < train_scratch_bytes():
+        raise RuntimeError("training scratch buffer is smaller than mgn_train_scratch_bytes()")
+    return p
+
+
+def train_ln_bwd(v, gamma, gpre, dgamma, dbeta, scratch, g=None, gg=None, idx=None, relu_mask=False):
+    rows = v.shape[0]
+    if g is None and gg is None:
+        raise RuntimeError("train_ln_bwd: no upstream gradient")
+    if gg is not None and idx is None:
+        raise RuntimeError("train_ln_bwd: a gathered gradient needs its row index")
+    rc = _lib.lib().mgn_train_ln_bwd(_opt(g, torch.float32, (rows, H), "G"), _opt(gg, torch.float32, (None, H), "Gg"),
+                                     _opt(idx, torch.int32, (rows,), "idx"), _rows128(v, "v"),
+                                     _dev(gamma, torch.float32, (H,), "gamma"), int(bool(relu_mask)),
+                                     _rows128(gpre, "gpre", rows), _dev(dgamma, torch.float32, (H,), "dgamma"),
+                                     _dev(dbeta, torch.float32, (H,), "dbeta"), _scratch(scratch), rows, _stream())
+    _lib.check(rc, "mgn_train_ln_bwd")
+
+
+def train_linear_bwd(g, scratch, a=None, w=None, koff=0, mask=None, res=None, ga=None, dw=None, dw_koff=0, db=None):
+    """``dw`` is the full [128, ld] gradient tensor; its columns dw_koff .. dw_koff+127 are written."""
+    rows = g.shape[0]
+    if ga is None and dw is None:
+        raise RuntimeError("train_linear_bwd: nothing to compute")
+    if ga is not None and w is None:
+        raise RuntimeError("train_linear_bwd: the input gradient needs the weight")
+    if dw is not None and a is None:
+        raise RuntimeError("train_linear_bwd: the weight gradient needs the layer input")
+    dw_ptr, lddw = C.c_void_p(0), 0
+    if dw is not None:
+        _dev(dw, torch.float32, (H, None), "dW")
+        if dw_koff < 0 or dw_koff + H > dw.shape[1]:
+            raise RuntimeError("train_linear_bwd: dW column block out of range")
+        dw_ptr, lddw = C.c_void_p(dw.data_ptr() + 4 * dw_koff), dw.shape[1]
+    rc = _lib.lib().mgn_train_linear_bwd(
+        _rows128(g, "G"), _opt(a, torch.float32, (rows, H), "A"),
+        C.c_void_p(0) if w is None else _wblock(w, koff, "W"), 0 if w is None else w.shape[1], koff,
+        _opt(mask, torch.float32, (rows, H), "mask"), _opt(res, torch.float32, (rows, H), "res"),
+        _opt(ga, torch.float32, (rows, H), "GA"), dw_ptr, lddw, _opt(db, torch.float32, (H,), "db"),
+        _scratch(scratch), rows, _stream())
+    _lib.check(rc, "mgn_train_linear_bwd")
+
+
+def segment_sum(src, rowptr, out, order=None):
+    n = out.shape[0]
+    _dev(rowptr, torch.int32, (n + 1,), "rowptr")
+    rc = _lib.lib().mgn_segment_sum(_dev(src, torch.float32, (None, H), "src"), C.c_void_p(rowptr.data_ptr()),
+                                    _opt(order, torch.int32, (None,), "order"), _rows128(out, "out"), n, _stream())
+    _lib.check(rc, "mgn_segment_sum")
+
+
+def train_pad_features(feat, mean_std, out):
+    rows, f = feat.shape
+    if f > H:
+        raise RuntimeError("train_pad_features: more than 128 features")
+    rc = _lib.lib().mgn_train_pad_features(_dev(feat, torch.float32, (rows, f), "feat"), f,
+                                           _opt(mean_std, torch.float32, (2 * f,), "mean_std"),
+                                           _rows128(out, "out", rows), rows, _stream())
+    _lib.check(rc, "mgn_train_pad_features")
+
+
+def train_loss_fwd(decoded, target_norm, node_type, time_dim, loss3, scratch):
+    n = decoded.shape[0]
+    rc = _lib.lib().mgn_train_loss_fwd(_rows128(decoded, "decoded"),
+                                       _dev(target_norm, torch.float32, (time_dim, n, 3), "target_norm"),
+                                       _dev(node_type, torch.float32, (n, 5), "node_type"), time_dim, n,
+                                       _dev(loss3, torch.float32, (3,), "loss3"), _scratch(scratch), _stream())
+    _lib.check(rc, "mgn_train_loss_fwd")
+
+
+def train_loss_bwd(decoded, target_norm, node_type, grad3, time_dim, gdecoded):
+    n = decoded.shape[0]
+    rc = _lib.lib().mgn_train_loss_bwd(_rows128(decoded, "decoded"),
+                                       _dev(target_norm, torch.float32, (time_dim, n, 3), "target_norm"),
+                                       _dev(node_type, torch.float32, (n, 5), "node_type"),
+                                       _dev(grad3, torch.float32, (3,), "grad3"), time_dim, n,
+                                       _rows128(gdecoded, "gdecoded", n), _stream())
+    _lib.check(rc, "mgn_train_loss_bwd")

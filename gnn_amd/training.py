@@ -1,0 +1,244 @@
+"""Training step on the HIP kernels: ``loss(graph)`` with gradients for every parameter.
+
+Covers what run_train_multiscale.py:139-141 runs per batch -- ``model.loss(batch)`` then
+``loss.backward()`` -- for the reference's forward (core/meshgraphnet.py:168-211) and loss
+(:285-304).  The forward keeps each layer's inputs and the two hidden activations of every
+MLP; the backward walks the layers in reverse with the blocks of ``mgn_train.hip``.  Weight
+gradients are deterministic (no atomics).  ``torch.autograd`` only carries the three loss
+components out and the parameter gradients back; no arithmetic of the model runs in torch.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+
+from . import ops
+from ._lib import H
+
+
+def _empty(rows, dev):
+    return torch.empty(rows, H, dtype=torch.float32, device=dev)
+
+
+class _Scratch:
+    _by_dev: Dict[str, torch.Tensor] = {}
+
+    @classmethod
+    def get(cls, dev) -> torch.Tensor:
+        key = str(dev)
+        buf = cls._by_dev.get(key)
+        if buf is None:
+            buf = torch.empty(ops.train_scratch_bytes(), dtype=torch.uint8, device=dev)
+            cls._by_dev[key] = buf
+        return buf
+
+
+def _pad_cols(w: torch.Tensor) -> torch.Tensor:
+    """[128, F] -> [128, 128] with zero columns (first Linear of an encoder)."""
+    out = torch.zeros(H, H, dtype=torch.float32, device=w.device)
+    out[:, : w.shape[1]].copy_(w.detach())
+    return out
+
+
+def _pad_rows(w: torch.Tensor, b: torch.Tensor):
+    """[O, 128], [O] -> [128, 128], [128] with zero rows (last Linear of the decoder)."""
+    wp = torch.zeros(H, H, dtype=torch.float32, device=w.device)
+    bp = torch.zeros(H, dtype=torch.float32, device=w.device)
+    wp[: w.shape[0]].copy_(w.detach())
+    bp[: b.shape[0]].copy_(b.detach())
+    return wp, bp
+
+
+def forward_saving(model, graph, target_norm: torch.Tensor):
+    """Runs the forward pass with the training kernels.  Returns (loss3 [3], saved) where
+    ``saved`` holds what ``backward`` needs."""
+    if model.__dict__.get("halo") is not None:
+        raise NotImplementedError("training on a partitioned mesh is not implemented; train on one GPU per mesh")
+    dev = graph["mesh_pos"].device
+    if dev.type != "cuda":
+        raise RuntimeError("the training kernels run on the GPU only")
+    if model.node_out_dim != 3:
+        raise RuntimeError("loss: node_out_dim must be 3")
+    f32 = model._f32
+    topo = model.topology(graph)
+    n, e, T = topo.num_nodes, topo.num_edges, model.time_dim
+    scratch = _Scratch.get(dev)
+    node_f = model._node_feat_dim(graph)
+    if node_f != model.node_encoder[0].weight.shape[1]:
+        raise RuntimeError(f"node features have width {node_f} but node_in_dim is {model.node_encoder[0].weight.shape[1]}")
+
+    # features and normalisers (accumulating), as in the inference path
+    world, mesh, phi = f32(graph["world_pos"]), f32(graph["mesh_pos"]), f32(graph["phi"])
+    node_type = f32(graph["node_type"])
+    mat = f32(graph["mat_param"]) if model.with_mat_params else None
+    nfeat = torch.empty(n, node_f, dtype=torch.float32, device=dev)
+    efeat = torch.empty(e, 7, dtype=torch.float32, device=dev)
+    ops.node_features(world, mesh, phi, f32(graph["swelling_phi"]), node_type, mat, nfeat)
+    ops.edge_features(world, mesh, phi, topo.sender, topo.recv, efeat)
+    ms_n = model.node_features_normalizer.stats_for(nfeat, True, None)
+    ms_e = model.edge_features_normalizer.stats_for(efeat, True, None)
+    nf_pad, ef_pad = _empty(n, dev), _empty(e, dev)
+    ops.train_pad_features(nfeat, ms_n, nf_pad)
+    ops.train_pad_features(efeat, ms_e, ef_pad)
+    del nfeat, efeat
+
+    def encoder(seq, inp):
+        w0p = _pad_cols(seq[0].weight)
+        h1, v, y = _empty(inp.shape[0], dev), _empty(inp.shape[0], dev), _empty(inp.shape[0], dev)
+        ops.train_linear_fwd(inp, w0p, 0, h1, bias=seq[0].bias.detach(), relu=True)
+        ops.train_linear_fwd(h1, seq[2].weight.detach(), 0, v, bias=seq[2].bias.detach())
+        ops.train_ln_fwd(v, seq[3].weight.detach(), seq[3].bias.detach(), y=y)
+        return y, (inp, h1, v)
+
+    x, enc_n = encoder(model.node_encoder, nf_pad)
+    el, enc_e = encoder(model.edge_encoder, ef_pad)
+
+    layers: List[tuple] = []
+    ps, pr, eprime = _empty(n, dev), _empty(n, dev), _empty(e, dev)
+    blocks = list(model.processors)
+    for i, blk in enumerate(blocks):
+        em, nm = blk.edge_mlp, blk.node_mlp
+        w0 = em[0].weight.detach()
+        ops.train_linear_fwd(x, w0, 0, ps)
+        ops.train_linear_fwd(x, w0, H, pr, bias=em[0].bias.detach())
+        h1e, ve = _empty(e, dev), _empty(e, dev)
+        ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
+        ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
+        last = i + 1 == len(blocks)
+        e_next = None if last else _empty(e, dev)          # the edge latents after the last block are unused
+        ops.train_ln_fwd(ve, em[4].weight.detach(), em[4].bias.detach(), y=eprime,
+                         res=None if last else el, yres=e_next)
+        aggr = _empty(n, dev)
+        ops.segment_sum(eprime, topo.rowptr, aggr)
+        h1n, vn, x_next = _empty(n, dev), _empty(n, dev), _empty(n, dev)
+        ops.train_linear_fwd(x, nm[0].weight.detach(), 0, h1n, b=aggr, koff_b=H, bias=nm[0].bias.detach(), relu=True)
+        ops.train_linear_fwd(h1n, nm[2].weight.detach(), 0, vn, bias=nm[2].bias.detach(), relu=True)
+        ops.train_ln_fwd(vn, nm[4].weight.detach(), nm[4].bias.detach(), res=x, yres=x_next)
+        layers.append((x, el, h1e, ve, aggr, h1n, vn))
+        x, el = x_next, e_next
+
+    dec = model.node_decoder
+    hd, decoded = _empty(n, dev), _empty(n, dev)
+    ops.train_linear_fwd(x, dec[0].weight.detach(), 0, hd, bias=dec[0].bias.detach(), relu=True)
+    w2p, b2p = _pad_rows(dec[2].weight, dec[2].bias)
+    ops.train_linear_fwd(hd, w2p, 0, decoded, bias=b2p)
+    loss3 = torch.empty(3, dtype=torch.float32, device=dev)
+    ops.train_loss_fwd(decoded, target_norm, node_type, T, loss3, scratch)
+    saved = dict(topo=topo, enc_n=enc_n, enc_e=enc_e, layers=layers, x_last=x, hd=hd, decoded=decoded, w2p=w2p,
+                 target_norm=target_norm, node_type=node_type)
+    return loss3, saved
+
+
+def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Gradients of ``sum_c grad3[c] * loss3[c]`` for every parameter, keyed like ``named_parameters``."""
+    topo = saved["topo"]
+    dev = grad3.device
+    n, e, T = topo.num_nodes, topo.num_edges, model.time_dim
+    scratch = _Scratch.get(dev)
+    grads: Dict[str, torch.Tensor] = {}
+
+    def g_like(p):
+        return torch.empty_like(p, dtype=torch.float32)
+
+    def vec():
+        return torch.empty(H, dtype=torch.float32, device=dev)
+
+    # ---- decoder
+    dec = model.node_decoder
+    n_out = dec[2].weight.shape[0]
+    gdec = _empty(n, dev)
+    ops.train_loss_bwd(saved["decoded"], saved["target_norm"], saved["node_type"], grad3.contiguous(), T, gdec)
+    dw2p, db2p = torch.empty(H, H, dtype=torch.float32, device=dev), vec()
+    gh = _empty(n, dev)
+    ops.train_linear_bwd(gdec, scratch, a=saved["hd"], w=saved["w2p"], mask=saved["hd"], ga=gh, dw=dw2p, db=db2p)
+    grads["node_decoder.2.weight"] = dw2p[:n_out].contiguous()
+    grads["node_decoder.2.bias"] = db2p[:n_out].contiguous()
+    gx = gdec                                     # reuse: gradient wrt the node latents entering the decoder
+    dw, db = g_like(dec[0].weight), vec()
+    ops.train_linear_bwd(gh, scratch, a=saved["x_last"], w=dec[0].weight.detach(), ga=gx, dw=dw, db=db)
+    grads["node_decoder.0.weight"], grads["node_decoder.0.bias"] = dw, db
+
+    # ---- processor blocks in reverse
+    ge = None                                     # gradient wrt the edge latents leaving the block
+    g2n, g1n, gaggr, dps, dpr = (_empty(n, dev) for _ in range(5))
+    g2e, g1e = _empty(e, dev), _empty(e, dev)
+    s_rowptr, s_order = topo.sender_view()
+    blocks = list(model.processors)
+    for i in range(len(blocks) - 1, -1, -1):
+        blk, pre = blocks[i], f"processors.{i}."
+        em, nm = blk.edge_mlp, blk.node_mlp
+        x, el, h1e, ve, aggr, h1n, vn = saved["layers"][i]
+        # node MLP: x_next = x + LN(ReLU(V2 ReLU(V1 [x, aggr] + c1) + c2))
+        dg, dbt = vec(), vec()
+        ops.train_ln_bwd(vn, nm[4].weight.detach(), g2n, dg, dbt, scratch, g=gx, relu_mask=True)
+        grads[pre + "node_mlp.4.weight"], grads[pre + "node_mlp.4.bias"] = dg, dbt
+        dw, db = g_like(nm[2].weight), vec()
+        ops.train_linear_bwd(g2n, scratch, a=h1n, w=nm[2].weight.detach(), mask=h1n, ga=g1n, dw=dw, db=db)
+        grads[pre + "node_mlp.2.weight"], grads[pre + "node_mlp.2.bias"] = dw, db
+        dw, db = g_like(nm[0].weight), vec()
+        w_n0 = nm[0].weight.detach()
+        ops.train_linear_bwd(g1n, scratch, a=x, w=w_n0, koff=0, res=gx, ga=gx, dw=dw, dw_koff=0, db=db)
+        ops.train_linear_bwd(g1n, scratch, a=aggr, w=w_n0, koff=H, ga=gaggr, dw=dw, dw_koff=H)
+        grads[pre + "node_mlp.0.weight"], grads[pre + "node_mlp.0.bias"] = dw, db
+        # edge MLP: e' = LN(ReLU(W2 ReLU(ps[s] + pr[r] + W0e e) + b2)); upstream = ge + gaggr[receiver]
+        dg, dbt = vec(), vec()
+        ops.train_ln_bwd(ve, em[4].weight.detach(), g2e, dg, dbt, scratch, g=ge, gg=gaggr, idx=topo.recv, relu_mask=True)
+        grads[pre + "edge_mlp.4.weight"], grads[pre + "edge_mlp.4.bias"] = dg, dbt
+        dw, db = g_like(em[2].weight), vec()
+        ops.train_linear_bwd(g2e, scratch, a=h1e, w=em[2].weight.detach(), mask=h1e, ga=g1e, dw=dw, db=db)
+        grads[pre + "edge_mlp.2.weight"], grads[pre + "edge_mlp.2.bias"] = dw, db
+        dw0, db0 = g_like(em[0].weight), vec()
+        w_e0 = em[0].weight.detach()
+        if ge is None:
+            ge = _empty(e, dev)
+            ops.train_linear_bwd(g1e, scratch, a=el, w=w_e0, koff=2 * H, ga=ge, dw=dw0, dw_koff=2 * H)
+        else:
+            ops.train_linear_bwd(g1e, scratch, a=el, w=w_e0, koff=2 * H, res=ge, ga=ge, dw=dw0, dw_koff=2 * H)
+        # per-node projections: ps = x W0s^T (sender side), pr = x W0r^T + b0 (receiver side)
+        ops.segment_sum(g1e, topo.rowptr, dpr)
+        ops.segment_sum(g1e, s_rowptr, dps, order=s_order)
+        ops.train_linear_bwd(dps, scratch, a=x, w=w_e0, koff=0, res=gx, ga=gx, dw=dw0, dw_koff=0)
+        ops.train_linear_bwd(dpr, scratch, a=x, w=w_e0, koff=H, res=gx, ga=gx, dw=dw0, dw_koff=H, db=db0)
+        grads[pre + "edge_mlp.0.weight"], grads[pre + "edge_mlp.0.bias"] = dw0, db0
+
+    # ---- encoders: y = LN(W1 ReLU(W0 feat + b0) + b1), no gradient wanted for the features
+    def encoder_bwd(seq, name, saved_enc, gy, g_a, g_b):
+        inp, h1, v = saved_enc
+        dg, dbt = vec(), vec()
+        ops.train_ln_bwd(v, seq[3].weight.detach(), g_a, dg, dbt, scratch, g=gy, relu_mask=False)
+        grads[name + ".3.weight"], grads[name + ".3.bias"] = dg, dbt
+        dw, db = g_like(seq[2].weight), vec()
+        ops.train_linear_bwd(g_a, scratch, a=h1, w=seq[2].weight.detach(), mask=h1, ga=g_b, dw=dw, db=db)
+        grads[name + ".2.weight"], grads[name + ".2.bias"] = dw, db
+        dwp, db = torch.empty(H, H, dtype=torch.float32, device=dev), vec()
+        ops.train_linear_bwd(g_b, scratch, a=inp, dw=dwp, db=db)
+        grads[name + ".0.weight"] = dwp[:, : seq[0].weight.shape[1]].contiguous()
+        grads[name + ".0.bias"] = db
+
+    encoder_bwd(model.node_encoder, "node_encoder", saved["enc_n"], gx, g2n, g1n)
+    if ge is None:                                # no processor blocks: the edge encoder does not reach the loss
+        ge = torch.zeros(e, H, dtype=torch.float32, device=dev)
+    encoder_bwd(model.edge_encoder, "edge_encoder", saved["enc_e"], ge, g2e, g1e)
+    return grads
+
+
+class _LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, graph, target_norm, *params):
+        loss3, saved = forward_saving(model, graph, target_norm)
+        ctx.model, ctx.saved_acts = model, saved
+        ctx.names = [k for k, _ in model.named_parameters()]
+        return loss3
+
+    @staticmethod
+    def backward(ctx, grad3):
+        grads = backward(ctx.model, ctx.saved_acts, grad3.to(torch.float32).contiguous())
+        ctx.saved_acts = None
+        return (None, None, None) + tuple(grads[k] for k in ctx.names)
+
+
+def loss_components(model, graph, target_norm):
+    """[3] tensor (ux, uy, phi) attached to the autograd graph of the model's parameters."""
+    params = [p for _, p in model.named_parameters()]
+    return _LossFn.apply(model, graph, target_norm, *params)

@@ -154,6 +154,67 @@ int mgn_decode(const float* x /*[N][H]*/, const mgn_mlp* dec, int32_t time_dim, 
 int mgn_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int32_t width, void* stream);
 int mgn_scatter_rows(const float* src, const int64_t* idx, float* dst, int64_t rows, int32_t width, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Training building blocks: loss(graph) + loss.backward() of run_train_multiscale.py:139-141,
+ * i.e. the forward of core/meshgraphnet.py:168-211 with the activations kept and its
+ * reverse.  Every Linear is handled as 128 -> 128 blocks; inputs narrower than 128 (encoder
+ * features, decoder outputs) are zero padded by the caller.  All activations are [rows,128]
+ * fp32, row-major.  Weight / bias gradients are deterministic (per-workgroup partials in
+ * `scratch`, reduced in block order).  `scratch` holds at least mgn_train_scratch_bytes().
+ * ------------------------------------------------------------------------------------- */
+int64_t mgn_train_scratch_bytes(void);
+
+/* nn.Linear forward (core/meshgraphnet.py:36-43 as used at :95-96, :116-117):
+ * out[r,f] = act( sum_k A[r,k] W[f,koff_a+k] (+ sum_k B[r,k] W[f,koff_b+k]) (+ bias[f])
+ *                 (+ P[idxP[r],f] + Q[idxQ[r],f]) ),  act = ReLU if relu else identity.
+ * W is [128, ldw] row-major; B, bias and the (P, idxP, Q, idxQ) group may be NULL. */
+int mgn_train_linear_fwd(const float* A, const float* B, const float* W, int32_t ldw, int32_t koff_a, int32_t koff_b,
+                         const float* bias, const float* P, const int32_t* idxP, const float* Q, const int32_t* idxQ,
+                         int32_t relu, float* out, int64_t rows, void* stream);
+
+/* nn.LayerNorm(128) forward (eps 1e-5, biased variance): y = LN(v) * gamma + beta (y may be
+ * NULL), yres = y + res (residual of core/meshgraphnet.py:118, :120; NULL to skip). */
+int mgn_train_ln_fwd(const float* v, const float* gamma, const float* beta, const float* res, float* y, float* yres,
+                     int64_t rows, void* stream);
+
+/* LayerNorm backward.  Upstream gradient of row r is G[r] (+ Gg[idx[r]]); either term may be
+ * NULL.  gpre = gradient wrt v, multiplied by (v > 0) when relu_mask (v is then the output of
+ * the ReLU that precedes the LayerNorm); dgamma[128], dbeta[128] are overwritten. */
+int mgn_train_ln_bwd(const float* G, const float* Gg, const int32_t* idx, const float* v, const float* gamma,
+                     int32_t relu_mask, float* gpre, float* dgamma, float* dbeta, void* scratch, int64_t rows,
+                     void* stream);
+
+/* nn.Linear backward for one 128-column block of the weight.  G = gradient wrt the layer's
+ * output rows, A = the block's input rows.
+ *   dW[f*lddw + k] = sum_r G[r,f] A[r,k]     (dW points at the block's first column; NULL to skip)
+ *   db[f]          = sum_r G[r,f]            (NULL to skip; needs dW)
+ *   GA[r,k]        = sum_f G[r,f] W[f,koff+k], then * (mask[r,k] > 0) if mask, then + res[r,k] if res
+ *                    (NULL to skip; GA may alias res). */
+int mgn_train_linear_bwd(const float* G, const float* A, const float* W, int32_t ldw, int32_t koff, const float* mask,
+                         const float* res, float* GA, float* dW, int32_t lddw, float* db, void* scratch, int64_t rows,
+                         void* stream);
+
+/* out[n,:] = sum over k in [rowptr[n], rowptr[n+1]) of src[order ? order[k] : k, :], rows added
+ * in order of k; empty segments give zero.  The receiver-wise scatter_add of
+ * core/meshgraphnet.py:113 (order NULL, CSR edge order) and its sender-wise counterpart in
+ * the backward pass. */
+int mgn_segment_sum(const float* src, const int32_t* rowptr, const int32_t* order, float* out, int64_t n_segments,
+                    void* stream);
+
+/* out[r, 0:n_feat] = (feat[r,:] - mean) / std (mean_std = [mean | std], NULL = copy), out[r, n_feat:128] = 0. */
+int mgn_train_pad_features(const float* feat, int32_t n_feat, const float* mean_std, float* out, int64_t rows,
+                           void* stream);
+
+/* Loss of core/meshgraphnet.py:293-304 for node_out_dim = 3.  decoded is the padded decoder
+ * output [N,128] (column 3t+c = step t, component c; delta = decoded * (t+1), :207-211),
+ * target_norm [T,N,3], node_type [N,5].  loss3[c] = mean_t sum over nodes with
+ * node_type[:,c+1] != 1 of (delta - target_norm)^2. */
+int mgn_train_loss_fwd(const float* decoded, const float* target_norm, const float* node_type, int32_t time_dim,
+                       int64_t n_nodes, float* loss3, void* scratch, void* stream);
+/* gdecoded [N,128] = gradient of sum_c grad3[c] * loss3[c] wrt decoded (zero in the padding). */
+int mgn_train_loss_bwd(const float* decoded, const float* target_norm, const float* node_type, const float* grad3,
+                       int32_t time_dim, int64_t n_nodes, float* gdecoded, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ __all__ = [
     "OracleConfig", "NormStats", "cells_to_edge_index", "receiver_csr", "grid_mesh",
     "init_state_dict", "mlp", "mp_layer", "mp_layer_csr_projected", "node_features",
     "edge_features", "forward", "predict", "loss", "rollout", "make_norms",
-    "synthetic_graph", "bending_node_type", "state_dict_digest",
+    "synthetic_graph", "bending_node_type", "state_dict_digest", "forced_relu_masks",
 ]
 
 
@@ -198,14 +198,44 @@ def make_norms(cfg: OracleConfig) -> Dict[str, NormStats]:
 
 
 # --------------------------------------------------------------------------- network
+_FORCED_MASKS = None
+
+
+class forced_relu_masks:
+    """Test hook: inside this context every ReLU of the network, in call order (node encoder,
+    edge encoder, per block edge MLP x2 then node MLP x2, decoder), multiplies by the next given
+    0/1 mask instead of deciding from its input.  With the activation pattern pinned the
+    network is smooth, so gradients computed elsewhere under the same pattern can be compared
+    tightly.  Outside the context the oracle is unchanged."""
+
+    def __init__(self, masks):
+        self.masks = list(masks)
+
+    def __enter__(self):
+        global _FORCED_MASKS
+        _FORCED_MASKS = iter(self.masks)
+        return self
+
+    def __exit__(self, *exc):
+        global _FORCED_MASKS
+        _FORCED_MASKS = None
+        return False
+
+
+def _relu(h: torch.Tensor) -> torch.Tensor:
+    if _FORCED_MASKS is None:
+        return F.relu(h)
+    return h * next(_FORCED_MASKS).to(h.dtype)
+
+
 def mlp(sd, prefix: str, x: torch.Tensor, *, final_relu: bool, layer_norm: bool) -> torch.Tensor:
     """Two-Linear MLP as both factories build it (core/meshgraphnet.py:33-45, :64-78):
     Linear(.0) ReLU Linear(.2) [ReLU] [LayerNorm at the next free index]."""
-    h = F.relu(F.linear(x, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"]))
+    h = _relu(F.linear(x, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"]))
     h = F.linear(h, sd[f"{prefix}.2.weight"], sd[f"{prefix}.2.bias"])
     nxt = 3
     if final_relu:
-        h = F.relu(h); nxt = 4
+        h = _relu(h); nxt = 4
     if layer_norm:
         h = F.layer_norm(h, (h.shape[-1],), sd[f"{prefix}.{nxt}.weight"], sd[f"{prefix}.{nxt}.bias"], 1e-5)
     return h
