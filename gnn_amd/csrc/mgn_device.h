@@ -76,10 +76,14 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 // LayerNorm over the 128 features of every tile row.  Each lane holds 16 of a row's
 // features and forms their mean m and centred sum of squares M2 locally (two passes over
 // registers); the 8 (m, M2) pairs of a row (4 waves x 2 lane halves) meet in `red`, LDS
-// float[2][8][TM], and combine exactly as a pooled variance:
+// float[TM][LN_RED_LD] (row j: m[0..7], M2[0..7], pad -- rows 80 bytes apart so that the 16-byte
+// reads of 16 consecutive rows fall on distinct banks), and combine exactly as a pooled variance:
 //   mean = avg(m_k),  M2 = sum(M2_k) + 16 * sum((m_k - mean)^2),  var = M2 / 128 (biased).
 // Contains one workgroup barrier; after it every wave has finished reading whatever tile
 // fed the accumulators.
+constexpr int LN_RED_LD = 20;
+constexpr int LN_RED_FLOATS = TM * LN_RED_LD;
+
 __device__ __forceinline__ void ln_local_stats(const f32x16& v, float* red, int w, int j, int h) {
     float s = 0.f;
 #pragma unroll
@@ -88,27 +92,32 @@ __device__ __forceinline__ void ln_local_stats(const f32x16& v, float* red, int 
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const float d = v[i] - m; q += d * d; }
-    red[(2 * w + h) * TM + j] = m;
-    red[8 * TM + (2 * w + h) * TM + j] = q;
+    red[j * LN_RED_LD + 2 * w + h] = m;
+    red[j * LN_RED_LD + 8 + 2 * w + h] = q;
 }
 
 __device__ __forceinline__ f32x16 ln_finish(f32x16 v, const float* red, int w, int j, int h,
                                             const float* gamma_lds, const float* beta_lds) {
-    float mk[8], mean = 0.f, m2 = 0.f;
+    const f32x4 ma = *(const f32x4*)(red + j * LN_RED_LD), mb = *(const f32x4*)(red + j * LN_RED_LD + 4);
+    const f32x4 qa = *(const f32x4*)(red + j * LN_RED_LD + 8), qb = *(const f32x4*)(red + j * LN_RED_LD + 12);
+    const float mk[8] = {ma[0], ma[1], ma[2], ma[3], mb[0], mb[1], mb[2], mb[3]};
+    float mean = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { mk[k] = red[k * TM + j]; mean += mk[k]; m2 += red[8 * TM + k * TM + j]; }
+    for (int k = 0; k < 8; ++k) mean += mk[k];
     mean *= 0.125f;
+    float m2 = ((qa[0] + qa[1]) + (qa[2] + qa[3])) + ((qb[0] + qb[1]) + (qb[2] + qb[3]));
     float between = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const float d = mk[k] - mean; between += d * d; }
     const float var = (m2 + 16.0f * between) * (1.0f / H);
     const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    const float shift = -mean * rstd;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const f32x4 ga = *(const f32x4*)(gamma_lds + 32 * w + 8 * g + 4 * h);
         const f32x4 be = *(const f32x4*)(beta_lds + 32 * w + 8 * g + 4 * h);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[4 * g + t] = (v[4 * g + t] - mean) * rstd * ga[t] + be[t];
+        for (int t = 0; t < 4; ++t) v[4 * g + t] = fmaf(fmaf(v[4 * g + t], rstd, shift), ga[t], be[t]);
     }
     return v;
 }

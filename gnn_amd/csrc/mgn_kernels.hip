@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float X[2][tile_floats(H / 4)];   // staged e_in tile, double buffered
     __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];     // hidden tile, then the edge output
     __shared__ __attribute__((aligned(16))) float vec[3][H];      // b1, ln_w, ln_b
-    __shared__ float red[16 * TM];
+    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
     __shared__ int rid[2][TM + 4];
     __shared__ int srange[2];
 
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float Es[tile_floats(H / 4)];      // pre-residual output tile (fp32)
     __shared__ __attribute__((aligned(16))) float Gs[tile_floats(H / 4)];      // ps[sender] + pr[receiver] per tile row
     __shared__ __attribute__((aligned(16))) float vec[3][H];                   // b1, ln_w, ln_b
-    __shared__ float red[16 * TM];
+    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
     __shared__ float cout[H], tcarry[H];
     __shared__ int srange[2];
 
@@ -325,12 +325,13 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
         WPlanes32 wa;
         load_wplanes32(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
         f32x4 nx[4];
-        unsigned so[4], ro[4];                       // element offsets of the sender / receiver rows this thread gathers
+        int sid[4], rid[4];                          // sender / receiver of the rows this thread gathers; kept raw so
+                                                     // that nothing waits for these loads in the iteration issuing them
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int r = min(srow + 8 * it, last);
             nx[it] = *(const f32x4*)(ein_g + (unsigned)(r * H + 4 * sq));
-            so[it] = (unsigned)snd_g[r] * H + 4 * sq; ro[it] = (unsigned)rcv_g[r] * H + 4 * sq;
+            sid[it] = snd_g[r]; rid[it] = rcv_g[r];
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) planes_store4(Xp, srow + 8 * it, 4 * sq, nx[it]);
@@ -341,27 +342,34 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
             const bool act = i < ntiles;
             const int rel = i * TM;
             f32x16 acc;
+            f32x4 ga[4], gb[4];
             if (act) {
-                // this tile's per-node projections, gathered as whole 512-byte rows (thread = row, chunk)
-                // and summed into Gs; next tile's rows and ids
-                f32x4 ga[4], gb[4];
+                // this tile's per-node projections, gathered as whole 512-byte rows (thread = row, chunk);
+                // next tile's rows and ids
 #pragma unroll
-                for (int it = 0; it < 4; ++it) { ga[it] = *(const f32x4*)(a.ps + so[it]); gb[it] = *(const f32x4*)(a.pr + ro[it]); }
+                for (int it = 0; it < 4; ++it) {
+                    ga[it] = *(const f32x4*)(a.ps + ((unsigned)sid[it] * H + 4 * sq));
+                    gb[it] = *(const f32x4*)(a.pr + ((unsigned)rid[it] * H + 4 * sq));
+                }
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int r = min(rel + TM + srow + 8 * it, last);
                     nx[it] = *(const f32x4*)(ein_g + (unsigned)(r * H + 4 * sq));
-                    so[it] = (unsigned)snd_g[r] * H + 4 * sq; ro[it] = (unsigned)rcv_g[r] * H + 4 * sq;
+                    sid[it] = snd_g[r]; rid[it] = rcv_g[r];
                 }
+                STAMP(6);
                 acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 acc = wave_gemm3_32<0, 4>(Xp, wa, j, h, acc);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) *(f32x4*)(Gs + toff(srow + 8 * it, sq, H / 4)) = ga[it] + gb[it];
             }
             STAMP(1);
             __syncthreads();                                                 // bm
             STAMP(2);
-            if (act) acc = wave_gemm3_32<4, 8>(Xp, wa, j, h, acc);
+            if (act) {
+                acc = wave_gemm3_32<4, 8>(Xp, wa, j, h, acc);
+                // the gathers have had both halves of the product to arrive
+#pragma unroll
+                for (int it = 0; it < 4; ++it) *(f32x4*)(Gs + toff(srow + 8 * it, sq, H / 4)) = ga[it] + gb[it];
+            }
             STAMP(3);
             __syncthreads();                                                 // b1: every wave is done reading Xp; Gs complete
             STAMP(4);
@@ -407,6 +415,10 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
             __syncthreads();                                                 // bm
             STAMP(2);
             if (k >= 0) {
+                // segment ends first: this consumes the receiver ids loaded one iteration ago, before
+                // the conditional stores below make the outstanding-load count unknown to the compiler
+                mask = (unsigned)__ballot(j < nvalid && ra != rb);          // bit r: row r ends its segment
+                gmask = (mask >> (16 * sg)) & 0xFFFFu;
                 float* eo = eout_g + (unsigned)(relk * H);
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {     // residual + coalesced store
@@ -416,8 +428,6 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
                 }
                 // receiver-segmented sum: thread (column sc, group sg) scans rows 16sg .. 16sg+15 in
                 // order; xr[r] = sum of the rows since the last segment end before r
-                mask = (unsigned)__ballot(j < nvalid && ra != rb);          // bit r: row r ends its segment
-                gmask = (mask >> (16 * sg)) & 0xFFFFu;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) xr[r] = Es[(16 * sg + r) * (H + 4) + sc];
                 part = 0.f;
@@ -486,7 +496,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float Ps[PROJ ? tile_floats(H / 4) : 4];
     __shared__ __attribute__((aligned(16))) float Pr[PROJ ? tile_floats(H / 4) : 4];
     __shared__ __attribute__((aligned(16))) float vec[5][H];       // b0, b1, ln_w, ln_b, next b0
-    __shared__ float red[16 * TM];
+    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     f32x4 wa[32], wb[16], ws[16], wr[16];
@@ -635,7 +645,7 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
     __shared__ __attribute__((aligned(16))) float Os[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float vec[3][H];       // b1, ln_w, ln_b
     __shared__ float ms[2 * MGN_MAX_FEAT];
-    __shared__ float red[16 * TM];
+    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     const int F = a.n_feat;
