@@ -76,15 +76,58 @@ __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 // LayerNorm over the 128 features of every tile row.  Each lane holds 16 of a row's
 // features and forms their mean m and centred sum of squares M2 locally (two passes over
 // registers); the 8 (m, M2) pairs of a row (4 waves x 2 lane halves) meet in `red`, LDS
-// float[TM][LN_RED_LD] (row j: m[0..7], M2[0..7], pad -- rows 80 bytes apart so that the 16-byte
-// reads of 16 consecutive rows fall on distinct banks), and combine exactly as a pooled variance:
+// float[2][8][TM], and combine exactly as a pooled variance:
 //   mean = avg(m_k),  M2 = sum(M2_k) + 16 * sum((m_k - mean)^2),  var = M2 / 128 (biased).
 // Contains one workgroup barrier; after it every wave has finished reading whatever tile
 // fed the accumulators.
+__device__ __forceinline__ void ln_local_stats(const f32x16& v, float* red, int w, int j, int h) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    const float m = s * (1.0f / 16.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const float d = v[i] - m; q += d * d; }
+    red[(2 * w + h) * TM + j] = m;
+    red[8 * TM + (2 * w + h) * TM + j] = q;
+}
+
+__device__ __forceinline__ f32x16 ln_finish(f32x16 v, const float* red, int w, int j, int h,
+                                            const float* gamma_lds, const float* beta_lds) {
+    float mk[8], mean = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { mk[k] = red[k * TM + j]; mean += mk[k]; m2 += red[8 * TM + k * TM + j]; }
+    mean *= 0.125f;
+    float between = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const float d = mk[k] - mean; between += d * d; }
+    const float var = (m2 + 16.0f * between) * (1.0f / H);
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const f32x4 ga = *(const f32x4*)(gamma_lds + 32 * w + 8 * g + 4 * h);
+        const f32x4 be = *(const f32x4*)(beta_lds + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[4 * g + t] = (v[4 * g + t] - mean) * rstd * ga[t] + be[t];
+    }
+    return v;
+}
+
+__device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, int j, int h,
+                                                 const float* gamma_lds, const float* beta_lds) {
+    ln_local_stats(v, red, w, j, h);
+    __syncthreads();
+    return ln_finish(v, red, w, j, h, gamma_lds, beta_lds);
+}
+
+// The same LayerNorm with the exchange buffer laid out per row: `red` is float[TM][LN_RED_LD]
+// (row j: m[0..7], M2[0..7], pad -- rows 80 bytes apart so that the 16-byte reads of 16
+// consecutive rows fall on distinct banks), read back with four 16-byte loads per lane.  Fewer
+// instructions; wants 16 transient registers, so kernels at their register limit use the form above.
 constexpr int LN_RED_LD = 20;
 constexpr int LN_RED_FLOATS = TM * LN_RED_LD;
 
-__device__ __forceinline__ void ln_local_stats(const f32x16& v, float* red, int w, int j, int h) {
+__device__ __forceinline__ void ln_local_stats_rows(const f32x16& v, float* red, int w, int j, int h) {
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) s += v[i];
@@ -96,7 +139,7 @@ __device__ __forceinline__ void ln_local_stats(const f32x16& v, float* red, int 
     red[j * LN_RED_LD + 8 + 2 * w + h] = q;
 }
 
-__device__ __forceinline__ f32x16 ln_finish(f32x16 v, const float* red, int w, int j, int h,
+__device__ __forceinline__ f32x16 ln_finish_rows(f32x16 v, const float* red, int w, int j, int h,
                                             const float* gamma_lds, const float* beta_lds) {
     const f32x4 ma = *(const f32x4*)(red + j * LN_RED_LD), mb = *(const f32x4*)(red + j * LN_RED_LD + 4);
     const f32x4 qa = *(const f32x4*)(red + j * LN_RED_LD + 8), qb = *(const f32x4*)(red + j * LN_RED_LD + 12);
@@ -122,12 +165,6 @@ __device__ __forceinline__ f32x16 ln_finish(f32x16 v, const float* red, int w, i
     return v;
 }
 
-__device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, int j, int h,
-                                                 const float* gamma_lds, const float* beta_lds) {
-    ln_local_stats(v, red, w, j, h);
-    __syncthreads();
-    return ln_finish(v, red, w, j, h, gamma_lds, beta_lds);
-}
 
 // store the accumulator (row j, features 32w..32w+31) into a [TM][H] LDS tile
 __device__ __forceinline__ void acc_to_tile(float* tile, f32x16 v, int w, int j, int h) {

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float X[2][tile_floats(H / 4)];   // staged e_in tile, double buffered
     __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];     // hidden tile, then the edge output
     __shared__ __attribute__((aligned(16))) float vec[3][H];      // b1, ln_w, ln_b
-    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
+    __shared__ float red[16 * TM];
     __shared__ int rid[2][TM + 4];
     __shared__ int srange[2];
 
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
             const int k = i - 2;                     // tile in its LayerNorm / store stage
             const int relk = k * TM, nvalid = min(TM, last + 1 - relk);
             if (k >= 0) {
-                acc = ln_finish(acc, red, w, j, h, vec[1], vec[2]);
+                acc = ln_finish_rows(acc, red, w, j, h, vec[1], vec[2]);
                 acc_to_tile(Es, acc, w, j, h);
             }
             STAMP(1);
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
                 acc = acc_from_vec(vec[0], w, h);
                 acc = wave_gemm3_32<0, 8>(Hp[(i - 1) & 1], wb, j, h, acc);
                 acc = relu16(acc);
-                ln_local_stats(acc, red, w, j, h);
+                ln_local_stats_rows(acc, red, w, j, h);
             }
             STAMP(5);
             __syncthreads();                                                 // b2
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) float Ps[PROJ ? tile_floats(H / 4) : 4];
     __shared__ __attribute__((aligned(16))) float Pr[PROJ ? tile_floats(H / 4) : 4];
     __shared__ __attribute__((aligned(16))) float vec[5][H];       // b0, b1, ln_w, ln_b, next b0
-    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
+    __shared__ float red[16 * TM];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     f32x4 wa[32], wb[16], ws[16], wr[16];
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
     __shared__ __attribute__((aligned(16))) float Os[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float vec[3][H];       // b1, ln_w, ln_b
     __shared__ float ms[2 * MGN_MAX_FEAT];
-    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
+    __shared__ float red[16 * TM];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     const int F = a.n_feat;

@@ -16,3 +16,11 @@ s.record()
 for _ in range(5): ops.mp_edge(ef, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, ef, aggr)
 t.record(); torch.cuda.synchronize()
 print(os.path.basename(_lib.LIB_PATH), "edge kernel ms:", s.elapsed_time(t) / 5)
+nw = layer.node_mlp.weights()
+w0, b0 = layer.edge_mlp[0].weight.data, layer.edge_mlp[0].bias.data
+xo = torch.empty_like(x)
+for _ in range(2): ops.mp_node_project(x, aggr, topo.rowptr, nw, w0, b0, xo, ps, pr)
+s.record()
+for _ in range(5): ops.mp_node_project(x, aggr, topo.rowptr, nw, w0, b0, xo, ps, pr)
+t.record(); torch.cuda.synchronize()
+print(os.path.basename(_lib.LIB_PATH), "node+project kernel ms:", s.elapsed_time(t) / 5)
