@@ -8,10 +8,10 @@ MI355X (gfx950) -- hand-written HIP kernels behind the reference's Python API.
 The arithmetic lives in ``libmgn_hip.so`` (C ABI: ``include/mgn_hip.h``); importing this
 package does not load it, the first kernel call does and raises if it is missing.
 """
-from .graph import MeshGraph, Topology  # noqa: F401
+from .graph import MeshGraph, Topology, batch_graphs, unbatch_nodes  # noqa: F401
 from .normalization import Normalizer  # noqa: F401
 from .meshgraphnet import MLP, EdgeNodeMessagePassing, EncodeProcessDecodeMultiScale  # noqa: F401
 from .datasetclass import cells_to_edge_index, grid_mesh, synthetic_frames  # noqa: F401
-from .rollout import rollout  # noqa: F401
+from .rollout import rollout, rollout_batched  # noqa: F401
 
 __version__ = "0.1.0"

@@ -64,6 +64,51 @@ class MeshGraph:
         return "MeshGraph(" + ", ".join(parts) + ")"
 
 
+NODE_FIELDS = ("mesh_pos", "world_pos", "phi", "swelling_phi", "node_type")
+
+
+def batch_graphs(graphs) -> "MeshGraph":
+    """Block-diagonal union of frames that share nothing: node fields are concatenated, the node
+    ids in ``edge_index`` / ``cells`` of frame b are shifted by the node count of the frames before
+    it.  This is how small meshes fill a GPU (several trajectories advance in one launch sequence);
+    no message crosses blocks, so every block's result equals its stand-alone result as long as the
+    normaliser statistics are the same.  ``mat_param`` is a per-frame constant broadcast to all
+    nodes by the feature builder (core/meshgraphnet.py:219), so all frames must agree on it."""
+    graphs = list(graphs)
+    if not graphs:
+        raise ValueError("batch_graphs: empty list")
+    out = MeshGraph()
+    first = graphs[0]
+    offsets, n = [], 0
+    for g in graphs:
+        offsets.append(n)
+        n += g["mesh_pos"].shape[0]
+    for k in first.keys():
+        v = first[k]
+        if k in NODE_FIELDS:
+            out[k] = torch.cat([g[k] for g in graphs], dim=0)
+        elif k == "target":
+            out[k] = torch.cat([g[k] for g in graphs], dim=1)
+        elif k == "edge_index":
+            out[k] = torch.cat([g[k] + o for g, o in zip(graphs, offsets)], dim=1)
+        elif k == "cells":
+            out[k] = torch.cat([g[k] + o for g, o in zip(graphs, offsets)], dim=0)
+        elif k == "mat_param":
+            for g in graphs[1:]:
+                if not torch.equal(g[k], v):
+                    raise ValueError("batch_graphs: frames with different mat_param cannot share a batch")
+            out[k] = v
+        else:
+            out[k] = v
+    out["batch_sizes"] = [g["mesh_pos"].shape[0] for g in graphs]
+    return out
+
+
+def unbatch_nodes(t: torch.Tensor, sizes, dim: int = 0):
+    """Splits a node-indexed tensor of a batched frame back into its blocks."""
+    return list(torch.split(t, list(sizes), dim=dim))
+
+
 class Topology:
     """Receiver-major edge order for one ``edge_index``: in-edges of node n are CSR edges
     rowptr[n] .. rowptr[n+1]-1; ``perm[j]`` is the position of CSR edge j in ``edge_index``."""

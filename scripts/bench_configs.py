@@ -29,14 +29,7 @@ def model_for(steps):
 
 def batched(frames, copies):
     """Block-diagonal union of `copies` independent states on one mesh topology."""
-    g = frames[0]
-    n = g["mesh_pos"].shape[0]
-    out = MeshGraph()
-    for k in ("mesh_pos", "world_pos", "phi", "swelling_phi", "node_type"):
-        out[k] = g[k].repeat(copies, *([1] * (g[k].dim() - 1)))
-    out["mat_param"] = g["mat_param"]
-    out["edge_index"] = torch.cat([g["edge_index"] + b * n for b in range(copies)], dim=1)
-    return out
+    return gnn_amd.batch_graphs([frames[0]] * copies)
 
 
 # --- bending rollout, 200 frames
@@ -47,6 +40,16 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 rollout(m, frames)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"bending 33x17 rollout: {200 / dt:.1f} steps/s ({dt / 200 * 1e3:.3f} ms/step), {3168 * 10 * 200 / dt / 1e6:.1f} M edge-updates/s")
+
+# --- 64 bending trajectories advanced together
+from gnn_amd.rollout import rollout_batched  # noqa: E402
+trajs = [gnn_amd.synthetic_frames(32, 16, n_frames=200, seed=s, lx=0.08, ly=0.01) for s in range(64)]
+rollout_batched(m, [t[:10] for t in trajs])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+rollout_batched(m, trajs)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+print(f"bending 33x17 x64 trajectories: {64 * 200 / dt:.0f} trajectory-steps/s ({dt / 200 * 1e3:.3f} ms per batched step, "
+      f"host-side frame merging included)")
 
 # --- 100k mesh, 15 MP steps, 1 and 8 trajectories
 for copies in (1, 8):

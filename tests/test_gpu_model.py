@@ -234,3 +234,26 @@ def test_unsupported_options_raise():
     m = EncodeProcessDecodeMultiScale(10, 7, sample_ratio=0.0, node_out_dim=3, with_mat_params=False, process_steps=1)
     with pytest.raises(RuntimeError):       # CPU tensors: no fallback
         m.predict(O.synthetic_graph(2, 2))
+
+
+def test_batched_rollout_equals_separate_rollouts():
+    """Block-diagonal batching (small meshes fill the GPU by advancing several trajectories at
+    once): with statistics that no longer accumulate, every trajectory's rollout equals its
+    stand-alone rollout up to summation order (the segmented sum associates the rows of a
+    receiver by their position in the 32-edge tiles, which shifts with the block offset)."""
+    import gnn_amd
+    from gnn_amd.rollout import rollout, rollout_batched
+    cfg = O.OracleConfig(process_steps=3)
+    sd = O.init_state_dict(cfg, 4)
+    model = build_model(cfg, sd)
+    norms = O.make_norms(cfg)
+    g = O.synthetic_graph(12, 8, seed=1)
+    O.predict(sd, cfg, norms, g)                              # some statistics to freeze
+    norms["output"].normalize(1e-3 * torch.randn(1, g["mesh_pos"].shape[0], 3, generator=torch.Generator().manual_seed(4)))
+    copy_norms_frozen(model, norms)
+    trajs = [gnn_amd.synthetic_frames(12, 8, n_frames=6, seed=s) for s in (1, 2, 3)]
+    both = rollout_batched(model, trajs)
+    for tr, rb in zip(trajs, both):
+        rs = rollout(model, tr)
+        assert rel_l2(rb["pred"], rs["pred"]) < 1e-6, rel_l2(rb["pred"], rs["pred"])
+        assert abs(float(rs["rmse_phi"]) - float(rb["rmse_phi"])) <= 1e-5 * float(rs["rmse_phi"])

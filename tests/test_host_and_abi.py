@@ -129,3 +129,23 @@ def test_mesh_graph_container():
     assert float(g.a.sum()) == 0.0
     g.b = torch.ones(2); assert g["b"].shape == (2,)
     assert g.to("cpu")["a"].device.type == "cpu"
+
+
+def test_batch_graphs_block_diagonal():
+    """Batched frames: node fields concatenated, node ids shifted per block, nothing shared."""
+    import gnn_amd
+    a = gnn_amd.synthetic_frames(3, 2, seed=1)[0]
+    b = gnn_amd.synthetic_frames(4, 3, seed=2)[0]
+    g = gnn_amd.batch_graphs([a, b])
+    na, nb = a["mesh_pos"].shape[0], b["mesh_pos"].shape[0]
+    assert g["batch_sizes"] == [na, nb] and g["mesh_pos"].shape[0] == na + nb
+    ea = a["edge_index"].shape[1]
+    assert torch.equal(g["edge_index"][:, :ea], a["edge_index"]) and torch.equal(g["edge_index"][:, ea:], b["edge_index"] + na)
+    assert int(g["edge_index"][:, :ea].max()) < na <= int(g["edge_index"][:, ea:].min())
+    assert torch.equal(g["cells"][a["cells"].shape[0]:], b["cells"] + na)
+    parts = gnn_amd.unbatch_nodes(g["phi"], g["batch_sizes"])
+    assert torch.equal(parts[0], a["phi"]) and torch.equal(parts[1], b["phi"])
+    b2 = gnn_amd.synthetic_frames(4, 3, seed=2)[0]
+    b2["mat_param"] = b2["mat_param"] * 2
+    with pytest.raises(ValueError):
+        gnn_amd.batch_graphs([a, b2])
