@@ -67,6 +67,10 @@ __device__ __forceinline__ f32x16 acc_from_vec(const float* vec_lds, int w, int 
     return acc;
 }
 
+__device__ __forceinline__ f32x16 zero16() {
+    return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+}
+
 __device__ __forceinline__ f32x16 relu16(f32x16 v) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
@@ -171,6 +175,87 @@ __device__ __forceinline__ void acc_to_tile(float* tile, f32x16 v, int w, int j,
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         *(f32x4*)(tile + toff(j, 8 * w + 2 * g + h, H / 4)) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+}
+
+// ---------------------------------------------------------------------------- two-term fp16 split
+// fp32 products on the fp16 matrix pipe.  Every fp32 operand is written as x = h1 + h2 + d with
+// h1 = fp16(x), h2 = fp16(x - h1) (both round-to-nearest; x - h1 is exact in fp32), so |d| <= 2^-22 |x|
+// while h2 is a normal fp16 (below 2^-14 the pipe still takes the subnormal h2, at 2^-25 absolute).
+// A product is the three partial products h1*h1 + h1*h2 + h2*h1 accumulated in fp32 by
+// v_mfma_f32_32x32x16_f16, smallest first; the dropped h2*h2 is <= 2^-22 of the product.
+// Weights are pre-scaled by W_SCALE (a power of two, exact) so that their second term stays
+// normal; the accumulator is multiplied back by W_UNSCALE where the bias is added.
+// Operands must stay below the fp16 range (65504 / W_SCALE for weights): larger values become inf.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr float W_SCALE = 128.0f, W_UNSCALE = 1.0f / 128.0f;
+
+__device__ __forceinline__ void split2_pair(float a, float b, unsigned& p1, unsigned& p2) {
+    const f32x2 v = {a, b};
+    const f16x2 h = __builtin_convertvector(v, f16x2);
+    const f32x2 r = v - __builtin_convertvector(h, f32x2);
+    const f16x2 l = __builtin_convertvector(r, f16x2);
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, l);
+}
+
+// four consecutive fp32 -> per plane two dwords (4 fp16)
+__device__ __forceinline__ void split2_pack4(const f32x4 v, u32x2& p1, u32x2& p2) {
+    unsigned a1, a2, b1, b2;
+    split2_pair(v[0], v[1], a1, a2);
+    split2_pair(v[2], v[3], b1, b2);
+    p1 = u32x2{a1, b1}; p2 = u32x2{a2, b2};
+}
+
+// A tile of `rows` x K fp16 in two planes: plane p, row r, column k at  p * plane + r * ld + k  (halves),
+// ld = K + 8 (16 bytes of padding per row keep the 16-byte reads of 16 consecutive rows on distinct banks).
+__device__ __forceinline__ void hplanes_store4(unsigned short* tile, int plane, int ld, int row, int k, const f32x4 v) {
+    u32x2 p1, p2;
+    split2_pack4(v, p1, p2);
+    unsigned short* d = tile + row * ld + k;
+    *(u32x2*)(d) = p1; *(u32x2*)(d + plane) = p2;
+}
+
+// Register-resident fp16 planes of the weights of 32 output features over 16*KS inputs
+// (v_mfma_f32_32x32x16_f16: lane (i = lane & 31, h = lane >> 5) feeds k = 16c + 8h + 0..7).
+template <int KS>
+struct WPlanesH { u32x4 p[2][KS]; };
+
+template <int KS>
+__device__ __forceinline__ void load_wplanes_h(WPlanesH<KS>& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
+    const float* row = W + (size_t)feat * ldw + koff + 8 * h;
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+        const f32x4 lo4 = *(const f32x4*)(row + 16 * c) * W_SCALE, hi4 = *(const f32x4*)(row + 16 * c + 4) * W_SCALE;
+        u32x2 a1, a2, b1, b2;
+        split2_pack4(lo4, a1, a2);
+        split2_pack4(hi4, b1, b2);
+        w.p[0][c] = u32x4{a1[0], a1[1], b1[0], b1[1]};
+        w.p[1][c] = u32x4{a2[0], a2[1], b2[0], b2[1]};
+    }
+}
+
+__device__ __forceinline__ f32x16 mfma32_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// acc[32 feats][32 rows] += W_SCALE * W * tile^T over k-steps [C0, C1) of 16 starting at column kbase
+template <int C0, int C1, int KS>
+__device__ __forceinline__ f32x16 wave_gemm_h(const unsigned short* tile, int plane, int ld, int kbase,
+                                              const WPlanesH<KS>& w, int j, int h, f32x16 acc) {
+    const unsigned short* r = tile + j * ld + kbase + 8 * h;
+#pragma unroll
+    for (int c = C0; c < C1; ++c) {
+        const u32x4 x1 = *(const u32x4*)(r + 16 * c), x2 = *(const u32x4*)(r + plane + 16 * c);
+        acc = mfma32_f16(w.p[1][c], x1, acc);   // h2 * h1
+        acc = mfma32_f16(w.p[0][c], x2, acc);   // h1 * h2
+        acc = mfma32_f16(w.p[0][c], x1, acc);   // h1 * h1
+    }
+    return acc;
 }
 
 // Blocks b and b + 8 share an XCD (and its L2); hand each XCD a contiguous run of ranges.

@@ -203,8 +203,6 @@ __device__ unsigned long long g_stamps[2][16];
 // bf16 MFMA runs beside vector-ALU work of another wave on the same SIMD, and the six products
 // cost 6/16 of the fp32 matrix time.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int PK = H + 8;                          // bf16 per plane row: 256 B of data + 16 B pad
 constexpr int PLANE = TM * PK;                     // bf16 per plane of a 32-row tile
@@ -585,6 +583,136 @@ __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
     }
 }
 
+// ======================================================================== processor: nodes, fp16-split products
+// The node update (and the next block's projections) with every product on the fp16 matrix pipe
+// (two-term split, three partial products): one 4-wave workgroup per CU, one wave per SIMD, all five
+// weight slices as fp16 planes in registers (320 of the 512 per lane).  With 120 short MFMAs per
+// 32-node tile instead of 320 fp32 ones the kernel is bound by its HBM rows, not by the matrix pipe.
+constexpr int PKH = H + 8;          // halves per plane row of a 128-column tile
+constexpr int PKH2 = 2 * H + 8;     // ... of the 256-column [x | aggr] tile
+
+template <bool PROJ>
+__global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short XAp[2 * TM * PKH2];   // [x | aggr] tile, 2 planes
+    __shared__ __attribute__((aligned(16))) float Xf[tile_floats(H / 4)];        // x rows in fp32 (residual)
+    __shared__ __attribute__((aligned(16))) unsigned short Hp[2 * TM * PKH];     // hidden tile, 2 planes
+    __shared__ __attribute__((aligned(16))) unsigned short Np[PROJ ? 2 * TM * PKH : 8];   // new x, 2 planes
+    __shared__ __attribute__((aligned(16))) float Os[tile_floats(H / 4)];        // new x in fp32 (store)
+    __shared__ __attribute__((aligned(16))) float Ps[PROJ ? tile_floats(H / 4) : 4];
+    __shared__ __attribute__((aligned(16))) float Pr[PROJ ? tile_floats(H / 4) : 4];
+    __shared__ __attribute__((aligned(16))) float vec[5][H];       // b0, b1, ln_w, ln_b, next b0
+    __shared__ float red[16 * TM];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    WPlanesH<16> wa;
+    WPlanesH<8> wb, ws, wr;
+    load_wplanes_h<16>(wa, a.w0, 2 * H, 0, 32 * w + j, h);
+    load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    if constexpr (PROJ) {
+        load_wplanes_h<8>(ws, a.nw0, 3 * H, 0, 32 * w + j, h);
+        load_wplanes_h<8>(wr, a.nw0, 3 * H, H, 32 * w + j, h);
+    }
+    if (t < H) {
+        vec[0][t] = a.b0[t]; vec[1][t] = a.b1[t]; vec[2][t] = a.ln_w[t]; vec[3][t] = a.ln_b[t];
+        vec[4][t] = PROJ ? a.nb0[t] : 0.f;
+    }
+    const int ntiles = (a.n_nodes + TM - 1) / TM;
+    const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+    const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
+    if (t0 >= t1) return;
+    const int srow = t >> 5, sq = t & 31;
+    const int nlast = a.n_nodes - 1;
+    constexpr int PL2 = TM * PKH2, PL = TM * PKH;
+
+    f32x4 px[4], pa[4];
+    auto prefetch = [&](int tile) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int n = min(tile * TM + srow + 8 * it, nlast);
+            px[it] = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+            // aggr rows of nodes without in-edges were never written: read them as zero
+            const bool has = a.rowptr[n + 1] > a.rowptr[n];
+            const f32x4 av = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
+            pa[it] = has ? av : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // accumulator (W_SCALE * product) -> value: acc * W_UNSCALE + bias, optional ReLU
+    auto finish = [&](f32x16 acc, const float* bias, bool relu) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *(const f32x4*)(bias + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float v = fmaf(acc[4 * g + k], W_UNSCALE, b[k]);
+                acc[4 * g + k] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+        return acc;
+    };
+    auto planes_from_acc = [&](unsigned short* tile, const f32x16& v) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            hplanes_store4(tile, PL, PKH, j, 32 * w + 8 * g + 4 * h, f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]});
+    };
+    prefetch(t0);
+    __syncthreads();
+    for (int tile = t0; tile < t1; ++tile) {
+        const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            *(f32x4*)(Xf + toff(row, sq, H / 4)) = px[it];
+            hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it]);
+            hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it]);
+        }
+        __syncthreads();                                             // (1) tile staged
+        prefetch(min(tile + 1, t1 - 1));
+        f32x16 acc = zero16();
+        acc = wave_gemm_h<0, 16, 16>(XAp, PL2, PKH2, 0, wa, j, h, acc);
+        acc = finish(acc, vec[0], true);
+        planes_from_acc(Hp, acc);
+        __syncthreads();                                             // (2) hidden tile complete
+        acc = zero16();
+        acc = wave_gemm_h<0, 8, 8>(Hp, PL, PKH, 0, wb, j, h, acc);
+        acc = finish(acc, vec[1], true);
+        acc = layernorm_rows(acc, red, w, j, h, vec[2], vec[3]);     // (3) barrier inside
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {                                // residual, in accumulator layout
+            const f32x4 xr = *(const f32x4*)(Xf + toff(j, 8 * w + 2 * g + h, H / 4));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[4 * g + k] += xr[k];
+        }
+        acc_to_tile(Os, acc, w, j, h);
+        if constexpr (PROJ) planes_from_acc(Np, acc);
+        __syncthreads();                                             // (4) new x complete
+        if constexpr (PROJ) {
+            f32x16 as = zero16(), ar = zero16();
+            as = wave_gemm_h<0, 8, 8>(Np, PL, PKH, 0, ws, j, h, as);
+            ar = wave_gemm_h<0, 8, 8>(Np, PL, PKH, 0, wr, j, h, ar);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) as[i] *= W_UNSCALE;
+            ar = finish(ar, vec[4], false);
+            acc_to_tile(Ps, as, w, j, h);
+            acc_to_tile(Pr, ar, w, j, h);
+            __syncthreads();                                         // (5) projections complete
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = srow + 8 * it;
+            if (row < nvalid) {
+                const size_t o = (size_t)(base + row) * H + 4 * sq;
+                *(f32x4*)(a.x_out + o) = *(const f32x4*)(Os + toff(row, sq, H / 4));
+                if constexpr (PROJ) {
+                    *(f32x4*)(a.ps + o) = *(const f32x4*)(Ps + toff(row, sq, H / 4));
+                    *(f32x4*)(a.pr + o) = *(const f32x4*)(Pr + toff(row, sq, H / 4));
+                }
+            }
+        }
+        // Xf / XAp are rewritten at the top of the next pass, after every thread's last read of them
+        // (before barrier 4 resp. 2); Os / Ps / Pr are rewritten only after the next pass's barriers
+    }
+}
+
 // ======================================================================== processor: projections
 struct ProjArgs { const float* x; const float* w0; const float* b0; float* ps; float* pr; int n_nodes; };
 
@@ -885,14 +1013,16 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const long lon
     }
 }
 
-// Edge-kernel matrix path: 1 = split-bf16 (three exact bf16 terms per fp32 operand, six partial
-// products, fp32 accumulation; the default), 0 = fp32 MFMA.  Both meet the same fp32 tolerance;
-// the environment variable MGN_MATMUL=f32|bf16x3 chooses explicitly.
+// Matrix path of the processor kernels (environment variable MGN_MATMUL):
+//   f16x2  (default) edge kernel: three-term bf16 split; node kernel: two-term fp16 split
+//   bf16x3           edge kernel: three-term bf16 split; node kernel: fp32 MFMA
+//   f32              fp32 MFMA everywhere
+// All meet the same fp32 tolerance; the fp16 split additionally needs |activations| < 65504.
 int matmul_mode() {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("MGN_MATMUL");
-        mode = (e && !strcmp(e, "f32")) ? 0 : 1;
+        mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "bf16x3")) ? 1 : 2;
     }
     return mode;
 }
@@ -935,7 +1065,7 @@ extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, 
     MGN_REQUIRE(n_nodes * (int64_t)H < (1ll << 31), "mgn_mp_edge");
     EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
                e_out, aggr, (int)n_edges, (int)n_nodes};
-    if (matmul_mode() == 1) {
+    if (matmul_mode() >= 1) {
         const int g = grid_for((n_edges + TM - 1) / TM, 1);
         hipLaunchKernelGGL(mp_edge3_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);
     } else {
@@ -954,8 +1084,13 @@ static int launch_node(const float* x, const float* aggr, const int32_t* rowptr,
     NodeArgs a{x, aggr, rowptr, m->w0, m->b0, m->w1, m->b1, m->ln_w, m->ln_b, next_w0, next_b0, x_out, ps, pr,
                (int)n_nodes};
     const int g = grid_for((n_nodes + TM - 1) / TM, 1);
-    if (next_w0) hipLaunchKernelGGL((mp_node_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((mp_node_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    if (matmul_mode() == 2) {
+        if (next_w0) hipLaunchKernelGGL((mp_node_h_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mp_node_h_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    } else {
+        if (next_w0) hipLaunchKernelGGL((mp_node_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((mp_node_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    }
     return check_launch(name);
 }
 

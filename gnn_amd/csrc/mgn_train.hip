@@ -30,10 +30,6 @@ __device__ __forceinline__ void load_wfrag_t(f32x4 (&w)[16], const float* __rest
     }
 }
 
-__device__ __forceinline__ f32x16 zero16() {
-    return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-}
-
 // contiguous tile range of this workgroup
 __device__ __forceinline__ void tile_range(long long rows, int& t0, int& t1) {
     const int ntiles = (int)((rows + TM - 1) / TM);
