@@ -144,7 +144,7 @@ __device__ __forceinline__ void ln_local_stats_rows(const f32x16& v, float* red,
 }
 
 __device__ __forceinline__ f32x16 ln_finish_rows(f32x16 v, const float* red, int w, int j, int h,
-                                            const float* gamma_lds, const float* beta_lds) {
+                                                 const float* gamma_lds, const float* beta_lds, float eps = LN_EPS) {
     const f32x4 ma = *(const f32x4*)(red + j * LN_RED_LD), mb = *(const f32x4*)(red + j * LN_RED_LD + 4);
     const f32x4 qa = *(const f32x4*)(red + j * LN_RED_LD + 8), qb = *(const f32x4*)(red + j * LN_RED_LD + 12);
     const float mk[8] = {ma[0], ma[1], ma[2], ma[3], mb[0], mb[1], mb[2], mb[3]};
@@ -157,7 +157,7 @@ __device__ __forceinline__ f32x16 ln_finish_rows(f32x16 v, const float* red, int
 #pragma unroll
     for (int k = 0; k < 8; ++k) { const float d = mk[k] - mean; between += d * d; }
     const float var = (m2 + 16.0f * between) * (1.0f / H);
-    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    const float rstd = 1.0f / sqrtf(var + eps);
     const float shift = -mean * rstd;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
