@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X dense bf16 matrix peak
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X dense fp16 matrix peak
 PEAK_HBM_GBS = 8000.0
 FLOP_PER_EDGE_CANONICAL = 2 * (384 * 128 + 128 * 128)      # 131072: reference edge MLP
 FLOP_PER_NODE_CANONICAL = 2 * (256 * 128 + 128 * 128)      # 98304: reference node MLP
@@ -168,7 +169,7 @@ def main():
             "unit": "edge-updates/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32 (2-term fp16 split operands, fp32 accumulate)" if os.environ.get("MGN_MATMUL", "f16x2") == "f16x2" else "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {args.grid}x{args.grid}-node triangle mesh, one rollout step (predict) "
                                    f"= {args.mp_steps} MP steps + encoder + decoder + integrator",
                        "nodes": n, "edges": e, "mp_steps": args.mp_steps, "latent": 128,
@@ -180,20 +181,33 @@ def main():
         if "mp_edge" in kern_ms:
             t_edge = kern_ms["mp_edge"] * 1e-3
             ach = FLOP_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e12
-            split = os.environ.get("MGN_MATMUL", "bf16x3") != "f32"
-            traffic = pmc_traffic("mp_edge3_kernel" if split else "mp_edge_kernel", e_local)
-            out["roofline"] = {"kernel": "mp_edge3_kernel" if split else "mp_edge_kernel", "bound": "mfma",
-                               "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                               "traffic": traffic, "traffic_unit": "bytes per launch (rocprofv3 PMC pass, see profiles/)",
+            mode = os.environ.get("MGN_MATMUL", "f16x2")
+            kernel, path, pipe_peak, products = {
+                "f32": ("mp_edge_kernel", "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, 1),
+                "bf16x3": ("mp_edge3_kernel", "fp32 operands split exactly into 3 bf16 terms, 6 partial products on "
+                           "v_mfma_f32_32x32x16_bf16, fp32 accumulate", PEAK_BF16_MFMA_TFLOPS, 6),
+            }.get(mode, ("mp_edge_h_kernel", "fp32 operands split into 2 fp16 terms (residual 2^-22), 3 partial products on "
+                         "v_mfma_f32_32x32x16_f16, fp32 accumulate", PEAK_F16_MFMA_TFLOPS, 3))
+            traffic = pmc_traffic(kernel, e_local)
+            bytes_alg = BYTES_PER_EDGE_EDGE_KERNEL * e_local
+            gbs = bytes_alg / t_edge / 1e9
+            t_floor_mfma = products * FLOP_PER_EDGE_EDGE_KERNEL * e_local / (pipe_peak * 1e12)
+            t_floor_hbm = bytes_alg / (PEAK_HBM_GBS * 1e9)
+            # the roof that binds is the one with the larger floor for this kernel's executed work
+            if t_floor_hbm >= t_floor_mfma:
+                roof = {"bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS}
+            else:
+                executed = products * ach
+                roof = {"bound": "mfma", "achieved": executed, "peak": pipe_peak, "unit": "TFLOP/s", "frac": executed / pipe_peak}
+            out["roofline"] = {"kernel": kernel, **roof, "traffic": traffic,
+                               "traffic_unit": "bytes per launch (rocprofv3 PMC pass, see profiles/)",
                                "avg_launch_ms": kern_ms["mp_edge"],
-                               "flop_per_edge": FLOP_PER_EDGE_EDGE_KERNEL,
-                               "hbm_GBs_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e9,
-                               "hbm_frac_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL * e_local / t_edge / 1e9 / PEAK_HBM_GBS,
-                               "matrix_path": ("fp32 operands split exactly into 3 bf16 terms, 6 partial products on "
-                                               "v_mfma_f32_32x32x16_bf16, fp32 accumulate" if split
-                                               else "v_mfma_f32_32x32x2_f32"),
-                               "matrix_pipe_frac": (6 * ach / PEAK_BF16_MFMA_TFLOPS) if split else ach / PEAK_F32_MFMA_TFLOPS}
+                               "bytes_per_edge_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL,
+                               "flop_per_edge_algorithmic": FLOP_PER_EDGE_EDGE_KERNEL,
+                               "fp32_equivalent_TFLOPs": ach, "fp32_equivalent_frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
+                               "matrix_path": path, "matrix_products_per_fp32_product": products,
+                               "matrix_pipe_frac": products * ach / pipe_peak,
+                               "floor_ms": {"hbm": t_floor_hbm * 1e3, "mfma": t_floor_mfma * 1e3}}
             # one MP step = everything the processor launches for one layer; the projection of
             # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
             n_layers = args.steps * args.mp_steps

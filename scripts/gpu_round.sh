@@ -8,6 +8,8 @@ timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout
 tail -2 gpurun_out/tests_default.log
 MGN_MATMUL=f32 timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/tests_f32.log 2>&1
 tail -2 gpurun_out/tests_f32.log
+MGN_MATMUL=bf16x3 timeout -k 10 500 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread > gpurun_out/tests_bf16x3.log 2>&1
+tail -2 gpurun_out/tests_bf16x3.log
 timeout -k 10 300 python bench.py > gpurun_out/bench.json 2> gpurun_out/bench.err
 cat gpurun_out/bench.json
 rm -rf gpurun_out/prof
