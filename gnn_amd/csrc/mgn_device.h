@@ -131,14 +131,19 @@ __device__ __forceinline__ f32x16 layernorm_rows(f32x16 v, float* red, int w, in
 constexpr int LN_RED_LD = 20;
 constexpr int LN_RED_FLOATS = TM * LN_RED_LD;
 
+__device__ __forceinline__ float sum16_tree(const f32x16& v) {
+    const float a = (v[0] + v[1]) + (v[2] + v[3]), b = (v[4] + v[5]) + (v[6] + v[7]);
+    const float c = (v[8] + v[9]) + (v[10] + v[11]), d = (v[12] + v[13]) + (v[14] + v[15]);
+    return (a + b) + (c + d);
+}
+
+// short dependency chains (pairwise sums) on purpose: the calling wave has nothing else to overlap with
 __device__ __forceinline__ void ln_local_stats_rows(const f32x16& v, float* red, int w, int j, int h) {
-    float s = 0.f;
+    const float m = sum16_tree(v) * (1.0f / 16.0f);
+    f32x16 d2;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) s += v[i];
-    const float m = s * (1.0f / 16.0f);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { const float d = v[i] - m; q += d * d; }
+    for (int i = 0; i < 16; ++i) { const float d = v[i] - m; d2[i] = d * d; }
+    const float q = sum16_tree(d2);
     red[j * LN_RED_LD + 2 * w + h] = m;
     red[j * LN_RED_LD + 8 + 2 * w + h] = q;
 }
@@ -147,17 +152,13 @@ __device__ __forceinline__ f32x16 ln_finish_rows(f32x16 v, const float* red, int
                                                  const float* gamma_lds, const float* beta_lds, float eps = LN_EPS) {
     const f32x4 ma = *(const f32x4*)(red + j * LN_RED_LD), mb = *(const f32x4*)(red + j * LN_RED_LD + 4);
     const f32x4 qa = *(const f32x4*)(red + j * LN_RED_LD + 8), qb = *(const f32x4*)(red + j * LN_RED_LD + 12);
-    const float mk[8] = {ma[0], ma[1], ma[2], ma[3], mb[0], mb[1], mb[2], mb[3]};
-    float mean = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) mean += mk[k];
-    mean *= 0.125f;
-    float m2 = ((qa[0] + qa[1]) + (qa[2] + qa[3])) + ((qb[0] + qb[1]) + (qb[2] + qb[3]));
-    float between = 0.f;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) { const float d = mk[k] - mean; between += d * d; }
+    const float mean = (((ma[0] + ma[1]) + (ma[2] + ma[3])) + ((mb[0] + mb[1]) + (mb[2] + mb[3]))) * 0.125f;
+    const float m2 = ((qa[0] + qa[1]) + (qa[2] + qa[3])) + ((qb[0] + qb[1]) + (qb[2] + qb[3]));
+    const f32x4 da = ma - mean, db = mb - mean;
+    const float between = ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) +
+                          ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
     const float var = (m2 + 16.0f * between) * (1.0f / H);
-    const float rstd = 1.0f / sqrtf(var + eps);
+    const float rstd = __builtin_amdgcn_rsqf(var + eps);      // v_rsq_f32, 1 ulp
     const float shift = -mean * rstd;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -168,7 +169,6 @@ __device__ __forceinline__ f32x16 ln_finish_rows(f32x16 v, const float* red, int
     }
     return v;
 }
-
 
 // store the accumulator (row j, features 32w..32w+31) into a [TM][H] LDS tile
 __device__ __forceinline__ void acc_to_tile(float* tile, f32x16 v, int w, int j, int h) {
@@ -243,17 +243,26 @@ __device__ __forceinline__ f32x16 mfma32_f16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
 }
 
-// acc[32 feats][32 rows] += W_SCALE * W * tile^T over k-steps [C0, C1) of 16 starting at column kbase
+// acc[32 feats][32 rows] += W_SCALE * W * tile^T over k-steps [C0, C1) of 16 starting at column kbase.
+// The two LDS reads of a k-step are issued one step ahead of the three MFMAs that consume them.
 template <int C0, int C1, int KS>
 __device__ __forceinline__ f32x16 wave_gemm_h(const unsigned short* tile, int plane, int ld, int kbase,
                                               const WPlanesH<KS>& w, int j, int h, f32x16 acc) {
     const unsigned short* r = tile + j * ld + kbase + 8 * h;
+    u32x4 x1 = *(const u32x4*)(r + 16 * C0), x2 = *(const u32x4*)(r + plane + 16 * C0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
     for (int c = C0; c < C1; ++c) {
-        const u32x4 x1 = *(const u32x4*)(r + 16 * c), x2 = *(const u32x4*)(r + plane + 16 * c);
+        u32x4 n1 = x1, n2 = x2;
+        if (c + 1 < C1) {
+            n1 = *(const u32x4*)(r + 16 * (c + 1)); n2 = *(const u32x4*)(r + plane + 16 * (c + 1));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // next step's reads first ...
+        }
         acc = mfma32_f16(w.p[1][c], x1, acc);   // h2 * h1
         acc = mfma32_f16(w.p[0][c], x2, acc);   // h1 * h2
         acc = mfma32_f16(w.p[0][c], x1, acc);   // h1 * h1
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);          // ... then this step's products
+        x1 = n1; x2 = n2;
     }
     return acc;
 }
