@@ -669,6 +669,156 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge_h_kernel(EdgeArgs a) {
     }
 }
 
+// ======================================================================== processor: edges, fp16 split, 4-wave workgroups
+// The edge update on the fp16 matrix pipe with the layout of mp_edge_kernel: two independent 4-wave
+// workgroups per CU (one wave of each per SIMD), every wave running both products of its tile.  The
+// two workgroups share nothing, so one's matrix phases overlap the other's vector / LDS phases without
+// any cross-role hand-over, and a 4-wave workgroup barrier costs tens of cycles where an 8-wave one
+// costs hundreds.  Per 32-edge tile i:
+//   top   request rows / ids of tile i+1, gather ps[s] + pr[r] of tile i (registers, accumulator layout)
+//   P1    product 1 from Xp[i&1]; ReLU, split -> Hp                                    barrier B
+//   P2    product 2 from Hp; ReLU, LayerNorm statistics -> red                         barrier C
+//   LN    LayerNorm finish -> Os (aliases Hp, which is dead by now)                    barrier D
+//   out   split + stage tile i+1 -> Xp[(i+1)&1]; receiver-segmented scan (16 rows per thread, the two
+//         halves chained through LDS: barrier S); residual (rows kept in registers) + coalesced store;
+//         segment sums -> aggr                                                         barrier E
+// All global stores of a tile come after its last wait for a load, so no wait drains the store queue.
+__global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[2][2 * PLH];     // e_in tile, 2 fp16 planes, double buffered
+    __shared__ __attribute__((aligned(16))) unsigned short Hp[2 * PLH];        // hidden tile, 2 fp16 planes; then Os
+    __shared__ __attribute__((aligned(16))) float vec[3][H];                   // W_SCALE * b1, ln_w, ln_b
+    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
+    __shared__ float cout[H], tcarry[H];             // open sum after row 15 / after the tile, per column
+    __shared__ int srange[2];
+    float* Os = (float*)Hp;                          // pre-residual output tile (fp32)
+    static_assert(sizeof(Hp) >= sizeof(float) * tile_floats(H / 4), "Os must fit into Hp");
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    WPlanesH<8> wa, wb;
+    load_wplanes_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
+    load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
+    if (t == 0) {
+        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+        const long long lo = (long long)rho * a.n_edges / nb, hi = (long long)(rho + 1) * a.n_edges / nb;
+        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
+        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
+    }
+    __syncthreads();
+    const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
+    if (e0 >= e1) return;
+    const int last = e1 - e0 - 1;                    // row offsets are relative to e0 and clamped to [0, last]
+    const float* ein_g = a.e_in + (size_t)e0 * H;
+    float* eout_g = a.e_out + (size_t)e0 * H;
+    const int* snd_g = a.sender + e0;
+    const int* rcv_g = a.recv + e0;
+    const int srow = t >> 5, sq = t & 31;            // row map: rows srow + 8*it, 16-byte chunk sq
+    const int sc = t & (H - 1);                      // scan map: column sc, rows 16*sg .. 16*sg+15
+    const int sg = __builtin_amdgcn_readfirstlane(t >> 7);
+
+    f32x4 cur[4], pre[4];                            // rows of this tile (residual) and of the next one
+#pragma unroll
+    for (int it = 0; it < 4; ++it) cur[it] = *(const f32x4*)(ein_g + (unsigned)(min(srow + 8 * it, last) * H + 4 * sq));
+    int s_cur = snd_g[min(j, last)], r_cur = rcv_g[min(j, last)];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) hplanes_store4(Xp[0], PLH, PKH, srow + 8 * it, 4 * sq, cur[it]);
+    __syncthreads();
+    STAMP_DECL
+    int b = 0;
+    for (int rel = 0; rel <= last; rel += TM, b ^= 1) {
+        STAMP(0);
+        const int nvalid = min(TM, last + 1 - rel);
+        // requests first: everything below waits only for loads that are at least a phase old
+        f32x4 gs[4], gr[4];
+        const unsigned so = (unsigned)s_cur * H + 32 * w + 4 * h, ro = (unsigned)r_cur * H + 32 * w + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gs[g] = *(const f32x4*)(a.ps + so + 8 * g); gr[g] = *(const f32x4*)(a.pr + ro + 8 * g); }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            pre[it] = *(const f32x4*)(ein_g + (unsigned)(min(rel + TM + srow + 8 * it, last) * H + 4 * sq));
+        const int s_nxt = snd_g[min(rel + TM + j, last)], r_nxt = rcv_g[min(rel + TM + j, last)];
+        const int ra = r_cur;                                                // receiver of tile row j ...
+        const int rb = (rel + j + 1 <= last) ? rcv_g[rel + j + 1] : -1;      // ... and of the row after it
+        STAMP(1);
+        f32x16 acc = zero16();
+        acc = wave_gemm_h<0, 8, 8>(Xp[b], PLH, PKH, 0, wa, j, h, acc);
+        STAMP(2);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(acc[4 * g + k], W_UNSCALE, gs[g][k] + gr[g][k]), 0.f);
+            hplanes_store4(Hp, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
+        }
+        STAMP(3);
+        __syncthreads();                                                     // (B) hidden tile complete
+        STAMP(4);
+        acc = acc_from_vec(vec[0], w, h);
+        acc = wave_gemm_h<0, 8, 8>(Hp, PLH, PKH, 0, wb, j, h, acc);
+        acc = relu16(acc);
+        ln_local_stats_rows(acc, red, w, j, h);
+        STAMP(5);
+        __syncthreads();                                                     // (C) statistics exchanged; Hp dead
+        STAMP(6);
+        acc = ln_finish_rows(acc, red, w, j, h, vec[1], vec[2], LN_EPS * W_SCALE * W_SCALE);
+        acc_to_tile(Os, acc, w, j, h);
+        STAMP(7);
+        __syncthreads();                                                     // (D) output tile complete
+        STAMP(8);
+        // next tile into the other plane buffer (its rows were requested at the top of this pass)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) hplanes_store4(Xp[b ^ 1], PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);
+        STAMP(9);
+        // receiver-segmented sum: thread (column sc, group sg) scans rows 16sg .. 16sg+15 in order;
+        // xr[r] = sum of the rows since the last segment end before r
+        const unsigned mask = (unsigned)__ballot(j < nvalid && ra != rb);   // bit r: row r ends its segment
+        const unsigned gmask = (mask >> (16 * sg)) & 0xFFFFu;
+        float xr[16], part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = Os[(16 * sg + r) * (H + 4) + sc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            part += xr[r];
+            xr[r] = part;
+            if ((gmask >> r) & 1u) part = 0.f;
+        }
+        float cin = tcarry[sc];                      // open segment of the previous tile (rewritten after S)
+        if (sg == 0) cout[sc] = gmask ? part : cin + part;
+        // residual for the store below, taken before Os can change
+        f32x4 y[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) y[it] = *(const f32x4*)(Os + toff(srow + 8 * it, sq, H / 4)) + cur[it];
+        STAMP(10);
+        __syncthreads();                                                     // (S) cout visible
+        STAMP(11);
+        if (sg == 1) cin = cout[sc];
+        {
+            float* eo = eout_g + (unsigned)(rel * H);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
+                if (row < nvalid) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y[it];
+            }
+        }
+        bool open = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((gmask >> r) & 1u) {
+                const int node = __builtin_amdgcn_readlane(ra, 16 * sg + r);
+                a.aggr[(unsigned)(node * H + sc)] = open ? cin + xr[r] : xr[r];
+                open = false;
+            }
+        }
+        if (sg == 1) tcarry[sc] = gmask ? part : cin + part;
+        STAMP(12);
+        __syncthreads();                                                     // (E) Os / Xp[b^1] / tcarry settled
+        s_cur = s_nxt; r_cur = r_nxt;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) cur[it] = pre[it];
+    }
+    STAMP_FLUSH(w == 0 ? 0 : (w == 2 ? 1 : -1))
+}
+
 // ======================================================================== processor: nodes
 // Node update, optionally followed by the NEXT layer's per-node projections of the freshly
 // updated latents (PROJ): one 4-wave workgroup per CU, all five weight slices in registers
@@ -1259,8 +1409,14 @@ extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, 
     EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
                e_out, aggr, (int)n_edges, (int)n_nodes};
     if (matmul_mode() == 2) {
-        const int g = grid_for((n_edges + TM - 1) / TM, 1);
-        hipLaunchKernelGGL(mp_edge_h_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);
+        static const int eight = getenv("MGN_EDGE_8WAVE") ? 1 : 0;   // diagnostic: the role-split 8-wave variant
+        if (eight) {
+            const int g = grid_for((n_edges + TM - 1) / TM, 1);
+            hipLaunchKernelGGL(mp_edge_h_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);
+        } else {
+            const int g = grid_for((n_edges + TM - 1) / TM, 2);
+            hipLaunchKernelGGL(mp_edge_h4_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+        }
     } else if (matmul_mode() == 1) {
         const int g = grid_for((n_edges + TM - 1) / TM, 1);
         hipLaunchKernelGGL(mp_edge3_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);

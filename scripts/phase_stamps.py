@@ -37,11 +37,12 @@ for it in range(3):
     torch.cuda.synchronize()
     lib.mgn_debug_read_stamps(buf, 1)
 vals = list(buf)
-names0 = {0: "wait b2 -> top", 6: "issue loads", 1: "product 1a", 2: "wait bm", 3: "product 1b", 4: "wait b1", 5: "ReLU/split -> Hp, stage next"}
-names1 = {0: "wait b2 -> top", 1: "LN finish -> Es", 2: "wait bm", 3: "store + scan", 4: "wait b1", 6: "scan finish", 5: "product 2 + stats"}
+names = {0: "barrier E -> top", 1: "requests: gathers, next rows, ids", 2: "product 1", 3: "ReLU, split -> Hp", 4: "barrier B",
+         5: "product 2, ReLU, LN statistics", 6: "barrier C", 7: "LN finish -> Os", 8: "barrier D", 9: "split + stage next tile",
+         10: "scan, residual sums", 11: "barrier S", 12: "e_out and aggr stores"}
 ntiles = (e + 31) // 32
-for wsel, label, names in ((0, "role 0, wave 0", names0), (1, "role 1, wave 4", names1)):
+for wsel, label in ((0, "wave 0"), (1, "wave 2")):
     tot = sum(vals[wsel * 16: wsel * 16 + 16])
-    print(label, "cycles per tile: %.0f" % (tot / ntiles))
-    for i in sorted(names, key=lambda q: [0, 6, 1, 2, 3, 4, 5].index(q) if wsel == 0 else [0, 1, 2, 3, 4, 6, 5].index(q)):
-        print("   %-30s %8.0f  %5.1f%%" % (names[i], vals[wsel * 16 + i] / ntiles, 100.0 * vals[wsel * 16 + i] / max(tot, 1)))
+    print(label, "cycles per tile (two workgroups share a CU: halve for the CU rate): %.0f" % (tot / ntiles))
+    for i in range(13):
+        print("   %-46s %8.0f  %5.1f%%" % (names[i], vals[wsel * 16 + i] / ntiles, 100.0 * vals[wsel * 16 + i] / max(tot, 1)))
