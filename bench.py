@@ -186,7 +186,7 @@ def main():
                 "f32": ("mp_edge_kernel", "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, 1),
                 "bf16x3": ("mp_edge3_kernel", "fp32 operands split exactly into 3 bf16 terms, 6 partial products on "
                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate", PEAK_BF16_MFMA_TFLOPS, 6),
-            }.get(mode, ("mp_edge_h_kernel", "fp32 operands split into 2 fp16 terms (residual 2^-22), 3 partial products on "
+            }.get(mode, ("mp_edge_h4_kernel", "fp32 operands split into 2 fp16 terms (residual 2^-22), 3 partial products on "
                          "v_mfma_f32_32x32x16_f16, fp32 accumulate", PEAK_F16_MFMA_TFLOPS, 3))
             traffic = pmc_traffic(kernel, e_local)
             bytes_alg = BYTES_PER_EDGE_EDGE_KERNEL * e_local

@@ -1059,17 +1059,26 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
 // ======================================================================== processor: projections
 struct ProjArgs { const float* x; const float* w0; const float* b0; float* ps; float* pr; int n_nodes; };
 
+template <bool HALF>
 __global__ __launch_bounds__(NT, 2) void mp_project_kernel(ProjArgs a) {
-    __shared__ __attribute__((aligned(16))) float X[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];  // x tile: fp16 planes or fp32
     __shared__ __attribute__((aligned(16))) float Ps[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float Pr[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float vec[H];
+    float* X = (float*)Xp;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
-    f32x4 ws[16], wr[16];
-    load_wfrag<16>(ws, a.w0, 3 * H, 0, 32 * w + j, h);
-    load_wfrag<16>(wr, a.w0, 3 * H, H, 32 * w + j, h);
-    if (t < H) vec[t] = a.b0[t];
+    f32x4 ws[HALF ? 1 : 16], wr[HALF ? 1 : 16];
+    WPlanesH<HALF ? 8 : 1> hs, hr;
+    if constexpr (HALF) {
+        load_wplanes_h<8>(hs, a.w0, 3 * H, 0, 32 * w + j, h);
+        load_wplanes_h<8>(hr, a.w0, 3 * H, H, 32 * w + j, h);
+    } else {
+        load_wfrag<16>(ws, a.w0, 3 * H, 0, 32 * w + j, h);
+        load_wfrag<16>(wr, a.w0, 3 * H, H, 32 * w + j, h);
+    }
+    constexpr float BS = HALF ? W_SCALE : 1.0f, US = HALF ? W_UNSCALE : 1.0f;
+    if (t < H) vec[t] = a.b0[t] * BS;
 
     const int ntiles = (a.n_nodes + TM - 1) / TM;
     const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
@@ -1081,13 +1090,22 @@ __global__ __launch_bounds__(NT, 2) void mp_project_kernel(ProjArgs a) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
-            *(f32x4*)(X + toff(row, sq, H / 4)) = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+            const f32x4 v = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, v);
+            else *(f32x4*)(X + toff(row, sq, H / 4)) = v;
         }
         __syncthreads();
-        f32x16 as = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 as = zero16();
         f32x16 ar = acc_from_vec(vec, w, h);
-        as = wave_gemm<16>(X, H / 4, 0, ws, j, h, as);
-        ar = wave_gemm<16>(X, H / 4, 0, wr, j, h, ar);
+        if constexpr (HALF) {
+            as = wave_gemm_h<0, 8, 8>(Xp, PLH, PKH, 0, hs, j, h, as);
+            ar = wave_gemm_h<0, 8, 8>(Xp, PLH, PKH, 0, hr, j, h, ar);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { as[i] *= US; ar[i] *= US; }
+        } else {
+            as = wave_gemm<16>(X, H / 4, 0, ws, j, h, as);
+            ar = wave_gemm<16>(X, H / 4, 0, wr, j, h, ar);
+        }
         acc_to_tile(Ps, as, w, j, h);
         acc_to_tile(Pr, ar, w, j, h);
         __syncthreads();
@@ -1110,28 +1128,38 @@ struct EncArgs {
     float* out; int rows; int n_feat;
 };
 
+// First Linear on the vector ALU (F <= 16 inputs, weights of 4 output features per thread in registers,
+// F4 = ceil(F / 4) input chunks), ReLU, hidden tile written as fp16 planes; second Linear on the fp16
+// matrix pipe (two-term split, W_SCALE folded into the LayerNorm epsilon); LayerNorm; coalesced store.
+// HALF = false keeps the second Linear on the fp32 matrix pipe (no fp16 range limit on the hidden values).
+template <int F4, bool HALF>
 __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
-    __shared__ __attribute__((aligned(16))) float Fs[TM * MGN_MAX_FEAT];
-    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];
+    constexpr int FP = 4 * F4;                       // padded input width
+    __shared__ __attribute__((aligned(16))) float Fs[TM * FP];
+    __shared__ __attribute__((aligned(16))) unsigned short Hp[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];   // hidden tile: 2 fp16 planes, or fp32
+    float* Hs = (float*)Hp;
     __shared__ __attribute__((aligned(16))) float Os[tile_floats(H / 4)];
-    __shared__ __attribute__((aligned(16))) float vec[3][H];       // b1, ln_w, ln_b
+    __shared__ __attribute__((aligned(16))) float vec[3][H];       // W_SCALE * b1, ln_w, ln_b
     __shared__ float ms[2 * MGN_MAX_FEAT];
-    __shared__ float red[16 * TM];
+    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     const int F = a.n_feat;
-    f32x4 wb[16];
-    load_wfrag<16>(wb, a.w1, H, 0, 32 * w + j, h);
+    WPlanesH<HALF ? 8 : 1> wb;
+    f32x4 wf[HALF ? 1 : 16];
+    if constexpr (HALF) load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    else load_wfrag<16>(wf, a.w1, H, 0, 32 * w + j, h);
+    constexpr float BS = HALF ? W_SCALE : 1.0f;      // scale carried by the second product
     const int srow = t >> 5, sq = t & 31;
-    // first-layer weights of features 4*sq .. 4*sq+3, zero padded to MGN_MAX_FEAT inputs
-    float w0r[4][MGN_MAX_FEAT], b0r[4];
+    // first-layer weights of features 4*sq .. 4*sq+3, zero padded to FP inputs
+    float w0r[4][FP], b0r[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         b0r[i] = a.b0[4 * sq + i];
 #pragma unroll
-        for (int k = 0; k < MGN_MAX_FEAT; ++k) w0r[i][k] = (k < F) ? a.w0[(size_t)(4 * sq + i) * F + k] : 0.f;
+        for (int k = 0; k < FP; ++k) w0r[i][k] = (k < F) ? a.w0[(size_t)(4 * sq + i) * F + k] : 0.f;
     }
-    if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; }
+    if (t < H) { vec[0][t] = a.b1[t] * BS; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; }
     if (t < MGN_MAX_FEAT) {
         ms[t] = (a.mean_std && t < F) ? a.mean_std[t] : 0.f;
         ms[MGN_MAX_FEAT + t] = (a.mean_std && t < F) ? a.mean_std[F + t] : 1.f;
@@ -1142,9 +1170,8 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
     __syncthreads();
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.rows - base);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int idx = t + NT * it, row = idx >> 4, k = idx & 15;
+        for (int idx = t; idx < TM * FP; idx += NT) {
+            const int row = idx / FP, k = idx - row * FP;
             const int n = min(base + row, a.rows - 1);
             Fs[idx] = (k < F) ? (a.feat[(size_t)n * F + k] - ms[k]) / ms[MGN_MAX_FEAT + k] : 0.f;
         }
@@ -1154,8 +1181,8 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
             const int row = srow + 8 * it;
             f32x4 hv = {b0r[0], b0r[1], b0r[2], b0r[3]};
 #pragma unroll
-            for (int k4 = 0; k4 < MGN_MAX_FEAT / 4; ++k4) {
-                const f32x4 f = *(const f32x4*)(Fs + row * MGN_MAX_FEAT + 4 * k4);
+            for (int k4 = 0; k4 < F4; ++k4) {
+                const f32x4 f = *(const f32x4*)(Fs + row * FP + 4 * k4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -1163,12 +1190,16 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = fmaxf(hv[i], 0.f);
-            *(f32x4*)(Hs + toff(row, sq, H / 4)) = hv;
+            if constexpr (HALF) hplanes_store4(Hp, PLH, PKH, row, 4 * sq, hv);
+            else *(f32x4*)(Hs + toff(row, sq, H / 4)) = hv;
         }
         __syncthreads();
         f32x16 acc = acc_from_vec(vec[0], w, h);
-        acc = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, acc);
-        acc = layernorm_rows(acc, red, w, j, h, vec[1], vec[2]);
+        if constexpr (HALF) acc = wave_gemm_h<0, 8, 8>(Hp, PLH, PKH, 0, wb, j, h, acc);
+        else acc = wave_gemm<16>(Hs, H / 4, 0, wf, j, h, acc);
+        ln_local_stats_rows(acc, red, w, j, h);
+        __syncthreads();
+        acc = ln_finish_rows(acc, red, w, j, h, vec[1], vec[2], LN_EPS * BS * BS);
         acc_to_tile(Os, acc, w, j, h);
         __syncthreads();
 #pragma unroll
@@ -1177,8 +1208,8 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
             if (row < nvalid)
                 *(f32x4*)(a.out + (size_t)(base + row) * H + 4 * sq) = *(const f32x4*)(Os + toff(row, sq, H / 4));
         }
-        // Fs / Hs / Os of the next tile are written only after barriers every thread
-        // reaches after this store pass; red is rewritten after the next Hs barrier
+        // Fs / Hp / Os of the next tile are written only after barriers every thread
+        // reaches after this store pass; red is rewritten after the next Hp barrier
     }
 }
 
@@ -1189,18 +1220,32 @@ struct DecArgs {
     float* pred; int n_nodes; int time_dim; int out_dim;
 };
 
+template <bool HALF>
 __global__ __launch_bounds__(NT, 1) void decode_kernel(DecArgs a) {
-    __shared__ __attribute__((aligned(16))) float X[tile_floats(H / 4)];
-    __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];
+    __shared__ __attribute__((aligned(16))) unsigned short Xp[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];   // x tile: fp16 planes or fp32
+    __shared__ __attribute__((aligned(16))) unsigned short Hq[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];   // hidden tile
     __shared__ __attribute__((aligned(16))) float vec[H];
     __shared__ float ob[MGN_MAX_DEC_OUT], om[MGN_MAX_DEC_OUT], os[MGN_MAX_DEC_OUT];
+    float* X = (float*)Xp;
+    float* Hs = (float*)Hq;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     const int n_out = a.time_dim * a.out_dim;
-    f32x4 wa[16], wb[16];
-    load_wfrag<16>(wa, a.w0, H, 0, 32 * w + j, h);
-    load_wfrag<16>(wb, a.w1, H, 0, min(j, n_out - 1), h, w == 0 && j < n_out);   // rows >= n_out read as zero
-    if (t < H) vec[t] = a.b0[t];
+    constexpr float BS = HALF ? W_SCALE : 1.0f, US = HALF ? W_UNSCALE : 1.0f;
+    f32x4 wa[HALF ? 1 : 16], wb[HALF ? 1 : 16];
+    WPlanesH<HALF ? 8 : 1> ha, hb;
+    if constexpr (HALF) {
+        load_wplanes_h<8>(ha, a.w0, H, 0, 32 * w + j, h);
+        load_wplanes_h<8>(hb, a.w1, H, 0, min(j, n_out - 1), h);
+        if (!(w == 0 && j < n_out)) {                // rows >= n_out read as zero
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { hb.p[0][c] = u32x4{0, 0, 0, 0}; hb.p[1][c] = u32x4{0, 0, 0, 0}; }
+        }
+    } else {
+        load_wfrag<16>(wa, a.w0, H, 0, 32 * w + j, h);
+        load_wfrag<16>(wb, a.w1, H, 0, min(j, n_out - 1), h, w == 0 && j < n_out);   // rows >= n_out read as zero
+    }
+    if (t < H) vec[t] = a.b0[t] * BS;
     if (t < MGN_MAX_DEC_OUT) {
         ob[t] = (t < n_out) ? a.b1[t] : 0.f;
         om[t] = (a.pred && t < n_out) ? a.out_mean_std[t] : 0.f;
@@ -1216,17 +1261,31 @@ __global__ __launch_bounds__(NT, 1) void decode_kernel(DecArgs a) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
-            *(f32x4*)(X + toff(row, sq, H / 4)) = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+            const f32x4 v = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
+            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, v);
+            else *(f32x4*)(X + toff(row, sq, H / 4)) = v;
         }
         __syncthreads();
         f32x16 acc = acc_from_vec(vec, w, h);
-        acc = wave_gemm<16>(X, H / 4, 0, wa, j, h, acc);
-        acc = relu16(acc);
-        acc_to_tile(Hs, acc, w, j, h);
+        if constexpr (HALF) {
+            acc = wave_gemm_h<0, 8, 8>(Xp, PLH, PKH, 0, ha, j, h, acc);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[4 * g + k] * US, 0.f);
+                hplanes_store4(Hq, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
+            }
+        } else {
+            acc = wave_gemm<16>(X, H / 4, 0, wa, j, h, acc);
+            acc = relu16(acc);
+            acc_to_tile(Hs, acc, w, j, h);
+        }
         __syncthreads();
         if (w == 0) {
-            f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            o = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, o);
+            f32x16 o = zero16();
+            if constexpr (HALF) o = wave_gemm_h<0, 8, 8>(Hq, PLH, PKH, 0, hb, j, h, o);
+            else o = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, o);
             if (j < nvalid) {
                 const int n = base + j;
 #pragma unroll
@@ -1234,7 +1293,7 @@ __global__ __launch_bounds__(NT, 1) void decode_kernel(DecArgs a) {
                     const int oi = (reg & 3) + 8 * (reg >> 2) + 4 * h;     // decoder output index
                     if (oi < n_out) {
                         const int tt = oi / a.out_dim, k = oi - tt * a.out_dim;
-                        const float dn = (o[reg] + ob[oi]) * (float)(tt + 1);
+                        const float dn = (o[reg] * US + ob[oi]) * (float)(tt + 1);
                         if (a.delta_norm) a.delta_norm[((size_t)tt * a.n_nodes + n) * a.out_dim + k] = dn;
                         if (a.pred) {
                             float d = os[oi] * dn + om[oi];
@@ -1311,14 +1370,22 @@ __global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* _
     }
 }
 
-__global__ void feature_sums_final_kernel(const double* __restrict__ partial, int nblocks, int F,
-                                          double* __restrict__ sums) {
-    const int k = threadIdx.x;                     // 0 .. 2F-1
-    if (k >= 2 * F) return;
-    const int col = (k < F) ? k : MGN_MAX_FEAT + (k - F);
+// 256 threads: thread (c = t / 32, col = t % 32) adds the partials of blocks c, c+8, c+16, ... of
+// padded column col; the eight chunk sums are then added in chunk order (fixed order: deterministic).
+__global__ __launch_bounds__(NT) void feature_sums_final_kernel(const double* __restrict__ partial, int nblocks, int F,
+                                                                double* __restrict__ sums) {
+    __shared__ double sh[8][2 * MGN_MAX_FEAT];
+    const int col = threadIdx.x & (2 * MGN_MAX_FEAT - 1), c = threadIdx.x / (2 * MGN_MAX_FEAT);
     double acc = 0.0;
-    for (int b = 0; b < nblocks; ++b) acc += partial[(size_t)b * 2 * MGN_MAX_FEAT + col];
-    sums[k] = acc;
+    for (int b = c; b < nblocks; b += 8) acc += partial[(size_t)b * 2 * MGN_MAX_FEAT + col];
+    sh[c][col] = acc;
+    __syncthreads();
+    if (threadIdx.x < 2 * F) {
+        const int k = threadIdx.x, pc = (k < F) ? k : MGN_MAX_FEAT + (k - F);
+        double tot = 0.0;
+        for (int q = 0; q < 8; ++q) tot += sh[q][pc];
+        sums[k] = tot;
+    }
 }
 
 __global__ void norm_update_kernel(float* acc_sum, float* acc_sumsq, const double* sums, int F, float safe_count,
@@ -1394,7 +1461,8 @@ extern "C" int mgn_mp_project(const float* x, const float* edge_w0, const float*
     MGN_REQUIRE(x && edge_w0 && edge_b0 && ps && pr, "mgn_mp_project");
     ProjArgs a{x, edge_w0, edge_b0, ps, pr, (int)n_nodes};
     const int g = grid_for((n_nodes + TM - 1) / TM, 2);
-    hipLaunchKernelGGL(mp_project_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    if (matmul_mode() == 2) hipLaunchKernelGGL((mp_project_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((mp_project_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     return check_launch("mgn_mp_project");
 }
 
@@ -1501,7 +1569,7 @@ extern "C" int mgn_feature_sums(const float* feat, int64_t rows, int32_t n_feat,
     const int nb = sum_blocks(rows);
     hipLaunchKernelGGL(feature_sums_partial_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, feat,
                        (long long)rows, (int)n_feat, (double*)scratch);
-    hipLaunchKernelGGL(feature_sums_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(feature_sums_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream,
                        (const double*)scratch, nb, (int)n_feat, sums);
     return check_launch("mgn_feature_sums");
 }
@@ -1522,7 +1590,15 @@ extern "C" int mgn_encode(const float* feat, int32_t n_feat, const float* mean_s
     MGN_REQUIRE(feat && out && mlp_ok(enc, true), "mgn_encode");
     EncArgs a{feat, mean_std, enc->w0, enc->b0, enc->w1, enc->b1, enc->ln_w, enc->ln_b, out, (int)rows, (int)n_feat};
     const int g = grid_for((rows + TM - 1) / TM, 2);
-    hipLaunchKernelGGL(encode_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    const bool half = matmul_mode() == 2;
+    const int f4 = (n_feat + 3) / 4;
+#define MGN_LAUNCH_ENC(F4)                                                                                          \
+    do {                                                                                                            \
+        if (half) hipLaunchKernelGGL((encode_kernel<F4, true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);      \
+        else hipLaunchKernelGGL((encode_kernel<F4, false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);          \
+    } while (0)
+    if (f4 == 1) MGN_LAUNCH_ENC(1); else if (f4 == 2) MGN_LAUNCH_ENC(2); else if (f4 == 3) MGN_LAUNCH_ENC(3); else MGN_LAUNCH_ENC(4);
+#undef MGN_LAUNCH_ENC
     return check_launch("mgn_encode");
 }
 
@@ -1537,7 +1613,8 @@ extern "C" int mgn_decode(const float* x, const mgn_mlp* dec, int32_t time_dim, 
     DecArgs a{x, dec->w0, dec->b0, dec->w1, dec->b1, delta_norm, out_mean_std, world_pos, phi, node_type,
               pred, (int)n_nodes, (int)time_dim, (int)out_dim};
     const int g = grid_for((n_nodes + TM - 1) / TM, 1);
-    hipLaunchKernelGGL(decode_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    if (matmul_mode() == 2) hipLaunchKernelGGL((decode_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((decode_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     return check_launch("mgn_decode");
 }
 
