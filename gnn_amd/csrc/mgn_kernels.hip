@@ -63,7 +63,8 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
     if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; }
     if (t == 0) {
         const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long lo = (long long)rho * a.n_edges / nb, hi = (long long)(rho + 1) * a.n_edges / nb;
+        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
+        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
         srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
         srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
     }
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
     if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
     if (t == 0) {
         const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long lo = (long long)rho * a.n_edges / nb, hi = (long long)(rho + 1) * a.n_edges / nb;
+        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
+        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
         srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
         srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
     }
@@ -497,7 +499,8 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge_h_kernel(EdgeArgs a) {
     if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
     if (t == 0) {
         const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long lo = (long long)rho * a.n_edges / nb, hi = (long long)(rho + 1) * a.n_edges / nb;
+        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
+        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
         srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
         srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
     }
@@ -700,7 +703,8 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
     if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
     if (t == 0) {
         const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long lo = (long long)rho * a.n_edges / nb, hi = (long long)(rho + 1) * a.n_edges / nb;
+        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
+        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
         srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
         srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
     }
@@ -999,8 +1003,10 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
     };
     prefetch(t0);
     __syncthreads();
+    STAMP_DECL
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
+        STAMP(0);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it;
@@ -1008,17 +1014,25 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
             hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it]);
             hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it]);
         }
+        STAMP(1);
         __syncthreads();                                             // (1) tile staged
+        STAMP(2);
         prefetch(min(tile + 1, t1 - 1));
+        STAMP(3);
         f32x16 acc = zero16();
         acc = wave_gemm_h<0, 16, 16>(XAp, PL2, PKH2, 0, wa, j, h, acc);
+        STAMP(4);
         acc = finish(acc, vec[0], true);
         planes_from_acc(Hp, acc);
+        STAMP(5);
         __syncthreads();                                             // (2) hidden tile complete
+        STAMP(6);
         acc = zero16();
         acc = wave_gemm_h<0, 8, 8>(Hp, PL, PKH, 0, wb, j, h, acc);
         acc = finish(acc, vec[1], true);
+        STAMP(7);
         acc = layernorm_rows(acc, red, w, j, h, vec[2], vec[3]);     // (3) barrier inside
+        STAMP(8);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {                                // residual, in accumulator layout
             const f32x4 xr = *(const f32x4*)(Xf + toff(j, 8 * w + 2 * g + h, H / 4));
@@ -1027,7 +1041,9 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         }
         acc_to_tile(Os, acc, w, j, h);
         if constexpr (PROJ) planes_from_acc(Np, acc);
+        STAMP(9);
         __syncthreads();                                             // (4) new x complete
+        STAMP(10);
         if constexpr (PROJ) {
             f32x16 as = zero16(), ar = zero16();
             as = wave_gemm_h<0, 8, 8>(Np, PL, PKH, 0, ws, j, h, as);
@@ -1037,7 +1053,9 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
             ar = finish(ar, vec[4], false);
             acc_to_tile(Ps, as, w, j, h);
             acc_to_tile(Pr, ar, w, j, h);
+            STAMP(11);
             __syncthreads();                                         // (5) projections complete
+            STAMP(12);
         }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -1051,9 +1069,11 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
                 }
             }
         }
+        STAMP(13);
         // Xf / XAp are rewritten at the top of the next pass, after every thread's last read of them
         // (before barrier 4 resp. 2); Os / Ps / Pr are rewritten only after the next pass's barriers
     }
+    if constexpr (PROJ) { STAMP_FLUSH(w == 0 ? 0 : (w == 2 ? 1 : -1)) }
 }
 
 // ======================================================================== processor: projections

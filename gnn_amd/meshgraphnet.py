@@ -123,11 +123,21 @@ class EdgeNodeMessagePassing(nn.Module):
         if not projected:
             with ops.timed("mp_project"):
                 ops.mp_project(x[:n], self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps[:n], pr[:n])
-        if halo is not None:
+        if halo is None:
+            with ops.timed("mp_edge"):
+                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
+        else:
+            # the receivers whose in-edges all come from owned senders are updated while the halo
+            # rows of `ps` are in flight; the rest follows once they have arrived
             with ops.timed("halo_exchange"):
-                halo.exchange_rows(ps)
-        with ops.timed("mp_edge"):
-            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
+                pending = halo.exchange_rows(ps, async_op=True)
+            with ops.timed("mp_edge"):
+                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr, node_range=halo.interior)
+            if pending is not None:
+                pending.wait()
+            with ops.timed("mp_edge_boundary"):
+                for rng in halo.boundary:
+                    ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr, node_range=rng)
         with ops.timed("mp_node"):
             if next_block is None:
                 ops.mp_node(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, x[:n])

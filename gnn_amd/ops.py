@@ -130,16 +130,32 @@ def mp_project(x, w0, b0, ps, pr):
     _lib.check(rc, "mgn_mp_project")
 
 
-def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, aggr):
+def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, aggr, node_range=None):
+    """``node_range = (n0, n1, edge_count)`` restricts the launch to the receivers n0 .. n1-1 and
+    their ``edge_count`` in-edges (= rowptr[n1] - rowptr[n0], known to the caller on the host)."""
     ne, n = e_in.shape[0], ps.shape[0]
     if mlp.in_dim != 3 * H or mlp.out_dim != H:
         raise RuntimeError("mp_edge: edge MLP must be 3H -> H -> H")
+    if n * H >= 2 ** 31:
+        raise RuntimeError("mp_edge: node rows are addressed with 32-bit element offsets (at most 16 777 215 nodes per GPU)")
+    rp = _dev(rowptr, torch.int32, (None,), "rowptr")
+    if rowptr.shape[0] < aggr.shape[0] + 1:
+        raise RuntimeError("mp_edge: rowptr is shorter than the number of receivers + 1")
+    n_sub, e_sub = aggr.shape[0], ne
+    if node_range is not None:
+        n0, n1, e_sub = (int(v) for v in node_range)
+        if not (0 <= n0 <= n1 <= aggr.shape[0]) or not (0 <= e_sub <= ne):
+            raise RuntimeError(f"mp_edge: bad receiver sub-range {node_range}")
+        rp = C.c_void_p(rowptr.data_ptr() + 4 * n0)
+        n_sub = n1 - n0
+        if n_sub == 0 or e_sub == 0:
+            return
     rc = _lib.lib().mgn_mp_edge(_dev(e_in, torch.float32, (ne, H), "e_in"), _dev(ps, torch.float32, (n, H), "ps"),
-                                _dev(pr, torch.float32, (n, H), "pr"), _dev(rowptr, torch.int32, (n + 1,), "rowptr"),
+                                _dev(pr, torch.float32, (n, H), "pr"), rp,
                                 _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
                                 _dev(csr_recv, torch.int32, (ne,), "csr_recv"), mlp.ref(),
-                                _dev(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (n, H), "aggr"),
-                                ne, n, _stream())
+                                _dev(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (None, H), "aggr"),
+                                e_sub, n_sub, _stream())
     _lib.check(rc, "mgn_mp_edge")
 
 

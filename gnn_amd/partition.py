@@ -74,7 +74,28 @@ class HaloPlan:
         self.topology = Topology(torch.from_numpy(self.local_edge_index), self.num_local, device)
         self.send_idx = torch.from_numpy(self.send_local_ids).to(device)
         self.group = group
+        self._ranges(self.topology.rowptr.cpu().numpy())
         return self
+
+    def _ranges(self, rowptr: np.ndarray) -> None:
+        """Splits the owned receivers into the longest contiguous run whose in-edges all come from
+        owned senders (``interior``) and what is left on either side (``boundary``): the interior
+        edges can be updated while the halo rows are still in flight.  Each range is
+        (first node, end node, number of in-edges), ready for ``ops.mp_edge(node_range=...)``."""
+        n_own = self.num_owned
+        needs_halo = np.zeros(n_own + 1, dtype=bool)
+        ls, lr = self.local_edge_index[0], self.local_edge_index[1]
+        needs_halo[lr[ls >= n_own]] = True
+        needs_halo[n_own] = True                       # sentinel
+        best, start = (0, 0), 0
+        for stop in np.nonzero(needs_halo)[0]:         # maximal unflagged runs end at flagged nodes
+            if stop - start > best[1] - best[0]:
+                best = (start, int(stop))
+            start = int(stop) + 1
+        a, b = best
+        cnt = lambda n0, n1: int(rowptr[n1]) - int(rowptr[n0])
+        self.interior = (a, b, cnt(a, b))
+        self.boundary = [r for r in ((0, a, cnt(0, a)), (b, n_own, cnt(b, n_own))) if r[1] > r[0]]
 
     def local_graph(self, graph) -> MeshGraph:
         """The rank's slice of a full-mesh frame: per-node tensors restricted to
@@ -93,16 +114,17 @@ class HaloPlan:
                 out[k] = v
         return out
 
-    def exchange_rows(self, buf: torch.Tensor) -> torch.Tensor:
+    def exchange_rows(self, buf: torch.Tensor, async_op: bool = False):
         """``buf`` is [num_local, W]; rows [0, num_owned) are valid.  Fills the halo rows with
-        the owners' values and returns ``buf``."""
+        the owners' values.  Returns ``buf``, or with ``async_op`` a handle whose ``wait()`` makes
+        the current stream wait for the halo rows (None when there is nothing to wait for)."""
         if self.world_size == 1:
-            return buf
+            return None if async_op else buf
         send = buf.index_select(0, self.send_idx) if self.send_idx.numel() else buf.new_empty((0, buf.shape[1]))
         recv = buf[self.num_owned:]
-        dist.all_to_all_single(recv, send, output_split_sizes=self.recv_counts, input_split_sizes=self.send_counts,
-                               group=self.group)
-        return buf
+        work = dist.all_to_all_single(recv, send, output_split_sizes=self.recv_counts, input_split_sizes=self.send_counts,
+                                      group=self.group, async_op=async_op)
+        return work if async_op else buf
 
     def exchange_state(self, world_pos: torch.Tensor, phi: torch.Tensor):
         """Refreshes the halo rows of the per-step state (3 floats per halo node)."""

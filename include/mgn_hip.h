@@ -79,7 +79,11 @@ int mgn_mp_project(const float* x /*[N][H]*/, const float* edge_w0 /*[H][3H]*/, 
  * e_out = LN(ReLU(W1 ReLU(first Linear) + b1)) + e_in ; aggr[n] = sum of the
  * pre-residual outputs over the in-edges of n, added in CSR order (deterministic).
  * Rows of aggr belonging to nodes without in-edges are left untouched.
- * e_out may alias e_in.                                                               */
+ * e_out may alias e_in.
+ * Receiver sub-range: rowptr may point at entry n0 of a larger CSR (rowptr[0] need not be 0);
+ * n_nodes / n_edges then count the receivers n0 .. n0+n_nodes-1 and their in-edges, while
+ * every other pointer still addresses the full arrays.  Used to run the edges that need no
+ * remote sender rows while a halo exchange is in flight.                                    */
 int mgn_mp_edge(const float* e_in /*[E][H]*/, const float* ps, const float* pr,
                 const int32_t* rowptr, const int32_t* csr_sender, const int32_t* csr_recv,
                 const mgn_mlp* edge_mlp, float* e_out /*[E][H]*/, float* aggr /*[N][H]*/,

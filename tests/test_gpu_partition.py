@@ -25,20 +25,35 @@ def _thread_plan(ei, n, world, rank, bus):
     from gnn_amd.partition import HaloPlan
 
     class ThreadPlan(HaloPlan):
-        def exchange_rows(self, buf):
-            send = buf.index_select(0, self.send_idx)
-            bus.slots[self.rank] = (send, self.send_counts)
-            bus.barrier.wait()
-            off = self.num_owned
-            for q in range(self.world_size):
-                if q == self.rank:
-                    continue
-                s, counts = bus.slots[q]
-                start, cnt = sum(counts[: self.rank]), counts[self.rank]
-                buf[off: off + cnt] = s[start: start + cnt]
-                off += cnt
-            bus.barrier.wait()
-            return buf
+        def exchange_rows(self, buf, async_op=False):
+            """In-process transport.  With async_op the halo rows are only filled in by wait(), i.e.
+            after the launches the caller puts in between: anything that reads them too early sees
+            the previous contents and the comparison below fails."""
+            plan = self
+
+            def run():
+                send = buf.index_select(0, plan.send_idx)
+                bus.slots[plan.rank] = (send, plan.send_counts)
+                bus.barrier.wait()
+                off = plan.num_owned
+                for q in range(plan.world_size):
+                    if q == plan.rank:
+                        continue
+                    s, counts = bus.slots[q]
+                    start, cnt = sum(counts[: plan.rank]), counts[plan.rank]
+                    buf[off: off + cnt] = s[start: start + cnt]
+                    off += cnt
+                bus.barrier.wait()
+
+            if not async_op:
+                run()
+                return buf
+
+            class Pending:
+                def wait(self_inner):
+                    run()
+            buf[plan.num_owned:].fill_(float("nan"))      # stale halo rows must not be read before wait()
+            return Pending()
 
         def sum_hook(self, kind):
             total = self.global_nodes if kind == "node" else self.global_edges

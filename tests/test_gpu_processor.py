@@ -9,6 +9,8 @@ import torch
 import oracle as O
 from conftest import GOLDEN, rel_l2
 
+DEV = "cuda:0"
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
@@ -91,3 +93,28 @@ def test_mp_layer_empty_edges():
     xo, eo = _model_layer(sd, 0, dev)(x.to(dev), ei.to(dev), e.to(dev))
     assert eo.shape == (0, 128)
     assert rel_l2(xo, rx) < TOL
+
+
+def test_edge_update_in_receiver_subranges():
+    """Three launches over consecutive receiver sub-ranges give the same e_out / aggr as one launch
+    over all receivers (up to the association of a receiver's rows inside a 32-edge tile)."""
+    import gnn_amd
+    from gnn_amd import ops
+    g = gnn_amd.synthetic_frames(40, 30, seed=3)[0]
+    n, e = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
+    topo = gnn_amd.Topology(g["edge_index"], n, DEV)
+    torch.manual_seed(1)
+    layer = gnn_amd.EdgeNodeMessagePassing(128).to(DEV)
+    ew = layer.edge_mlp.weights()
+    x, ef = torch.randn(n, 128, device=DEV), torch.randn(e, 128, device=DEV)
+    ps, pr = torch.empty_like(x), torch.empty_like(x)
+    ops.mp_project(x, layer.edge_mlp[0].weight.data, layer.edge_mlp[0].bias.data, ps, pr)
+    e1, a1 = torch.empty_like(ef), torch.zeros_like(x)
+    ops.mp_edge(ef, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e1, a1)
+    rp = topo.rowptr.cpu()
+    e2, a2 = torch.full_like(ef, float("nan")), torch.full_like(x, float("nan"))
+    cuts = [0, 137, 900, n]
+    for n0, n1 in zip(cuts[:-1], cuts[1:]):
+        ops.mp_edge(ef, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e2, a2, node_range=(n0, n1, int(rp[n1] - rp[n0])))
+    assert bool(torch.isfinite(e2).all()) and bool(torch.isfinite(a2).all())
+    assert rel_l2(e2, e1) < 1e-6 and rel_l2(a2, a1) < 1e-6
