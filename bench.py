@@ -211,7 +211,7 @@ def main():
             # one MP step = everything the processor launches for one layer; the projection of
             # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
             n_layers = args.steps * args.mp_steps
-            t_mp = sum(sum(per.get(k, [])) for k in ("mp_project", "halo_exchange", "mp_edge", "mp_node")) * 1e-3 / n_layers
+            t_mp = sum(sum(per.get(k, [])) for k in ("mp_project", "halo_exchange", "mp_edge", "mp_edge_boundary", "mp_node")) * 1e-3 / n_layers
             canon = (FLOP_PER_EDGE_CANONICAL * e_local + FLOP_PER_NODE_CANONICAL * n_local) / t_mp / 1e12
             out["mp_step"] = {"ms": t_mp * 1e3, "edge_updates_per_s_per_gpu": e_local / t_mp,
                               "edge_updates_per_s": e / t_mp,

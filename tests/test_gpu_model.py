@@ -257,3 +257,43 @@ def test_batched_rollout_equals_separate_rollouts():
         rs = rollout(model, tr)
         assert rel_l2(rb["pred"], rs["pred"]) < 1e-6, rel_l2(rb["pred"], rs["pred"])
         assert abs(float(rs["rmse_phi"]) - float(rb["rmse_phi"])) <= 1e-5 * float(rs["rmse_phi"])
+
+
+def test_full_size_mesh_matches_oracle_on_a_crop():
+    """Parity at the benchmark's full size (1000 x 1000 nodes, 15 message-passing steps) through
+    locality: the prediction at a node depends only on its 15-hop neighbourhood, so the oracle run
+    on a 64 x 64-node corner crop (same per-node inputs, induced edges, same frozen statistics) must
+    reproduce the full-mesh GPU prediction at every crop node further than 15 hops from the cut."""
+    import gnn_amd
+    steps, side, crop = 15, 1000, 64
+    cfg = O.OracleConfig(process_steps=steps)
+    sd = O.init_state_dict(cfg, 7)
+    g = gnn_amd.synthetic_frames(side - 1, side - 1, seed=0)[0]
+    ids = torch.arange(side * side)
+    inside = ((ids % side) < crop) & ((ids // side) < crop)
+    new_id = torch.full((side * side,), -1, dtype=torch.long)
+    new_id[inside] = torch.arange(int(inside.sum()))
+    ei = g["edge_index"]
+    keep = inside[ei[0]] & inside[ei[1]]
+    gc = {k: g[k][inside] for k in ("mesh_pos", "world_pos", "phi", "swelling_phi", "node_type")}
+    gc["mat_param"], gc["edge_index"] = g["mat_param"], new_id[ei[:, keep]]
+    norms = O.make_norms(cfg)
+    O.forward(sd, cfg, norms, gc)                          # statistics from the crop, then frozen on both sides
+    norms["output"].normalize(1e-3 * torch.randn(1, crop * crop, 3, generator=torch.Generator().manual_seed(4)))
+    for v in norms.values():
+        v.max_accumulations = 0
+    ref = O.predict(sd, cfg, norms, gc)
+    model = build_model(cfg, sd)
+    copy_norms_frozen(model, norms)
+    out = model.predict(g.to(DEV)).cpu()
+    assert bool(torch.isfinite(out).all())
+    cx, cy = torch.arange(crop * crop) % crop, torch.arange(crop * crop) // crop
+    far = (cx < crop - steps - 1) & (cy < crop - steps - 1)
+    got = out[:, inside][:, far]
+    cur = torch.cat([gc["world_pos"], gc["phi"]], -1)[far]
+    assert rel_l2(got, ref[:, far]) < TOL
+    assert rel_l2(got - cur, ref[:, far] - cur) < 5 * TOL, rel_l2(got - cur, ref[:, far] - cur)
+    # and the cut matters where it should: nodes next to it differ
+    near = (cx == crop - 1) | (cy == crop - 1)
+    assert rel_l2(out[:, inside][:, near] - torch.cat([gc["world_pos"], gc["phi"]], -1)[near],
+                  ref[:, near] - torch.cat([gc["world_pos"], gc["phi"]], -1)[near]) > 1e-3
