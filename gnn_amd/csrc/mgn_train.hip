@@ -261,14 +261,23 @@ __global__ __launch_bounds__(NT, 2) void train_linear_bwd_kernel(LinBwdArgs a) {
     }
 }
 
-// out[(i / width) * ld + (i % width)] = sum over blocks of partial[b * stride + offset + i], in block order
-__global__ void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int stride, int offset,
-                                       int count, int width, int ld, float* __restrict__ out) {
+// out[(i / width) * ld + (i % width)] = sum over blocks of partial[b * stride + offset + i].  Eight
+// independent running sums per thread (blocks b = k mod 8) keep eight loads in flight; they are
+// combined pairwise in a fixed order, so the result does not depend on the launch.
+__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int stride,
+                                                             int offset, int count, int width, int ld,
+                                                             float* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * stride + offset + i];
-    out[(size_t)(i / width) * ld + (i % width)] = s;
+    const float* p = partial + offset + i;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= nblocks; b += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += p[(size_t)(b + k) * stride];
+    }
+    for (int k = 0; b < nblocks; ++b, ++k) s[k] += p[(size_t)b * stride];
+    out[(size_t)(i / width) * ld + (i % width)] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
 }
 
 // ------------------------------------------------------------------------ segmented row sums
@@ -410,9 +419,9 @@ extern "C" int mgn_train_ln_bwd(const float* G, const float* Gg, const int32_t* 
     if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX;
     hipLaunchKernelGGL(train_ln_bwd_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, G, Gg, idx, v, gamma,
                        relu_mask, gpre, (float*)scratch, (long long)rows);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(H), 0, (hipStream_t)stream, (const float*)scratch, g,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, (hipStream_t)stream, (const float*)scratch, g,
                        2 * H, 0, H, H, H, dgamma);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(H), 0, (hipStream_t)stream, (const float*)scratch, g,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, (hipStream_t)stream, (const float*)scratch, g,
                        2 * H, H, H, H, H, dbeta);
     return check_launch("mgn_train_ln_bwd");
 }
@@ -433,10 +442,10 @@ extern "C" int mgn_train_linear_bwd(const float* G, const float* A, const float*
     else if (GA) hipLaunchKernelGGL((train_linear_bwd_kernel<true, false>), dim3(g), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((train_linear_bwd_kernel<false, true>), dim3(g), dim3(NT), 0, s, a);
     if (dW) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(PARTIAL_W / NT), dim3(NT), 0, s, (const float*)scratch, g,
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(PARTIAL_W / 64), dim3(64), 0, s, (const float*)scratch, g,
                            PARTIAL, 0, PARTIAL_W, H, lddw, dW);
         if (db)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(H), 0, s, (const float*)scratch, g, PARTIAL,
+            hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, s, (const float*)scratch, g, PARTIAL,
                                PARTIAL_W, H, H, H, db);
     }
     return check_launch("mgn_train_linear_bwd");
