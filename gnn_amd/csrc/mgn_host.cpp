@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 static thread_local char g_err[512] = "";
@@ -120,4 +122,13 @@ extern "C" int mgn_receiver_csr(const int64_t* sender, const int64_t* recv, int6
         if (perm) perm[j] = i;
     }
     return 0;
+}
+
+int mgn_matmul_mode() {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("MGN_MATMUL");
+        mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "bf16x3")) ? 1 : 2;
+    }
+    return mode;
 }

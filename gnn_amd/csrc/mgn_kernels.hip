@@ -1448,14 +1448,7 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const long lon
 //   bf16x3           edge kernel: three-term bf16 split, six partial products; node kernel: fp32 MFMA
 //   f32              fp32 MFMA everywhere
 // All meet the same fp32 tolerance; the fp16 split additionally needs |activations| < 65504.
-int matmul_mode() {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("MGN_MATMUL");
-        mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "bf16x3")) ? 1 : 2;
-    }
-    return mode;
-}
+int matmul_mode() { return mgn_matmul_mode(); }
 
 bool mlp_ok(const mgn_mlp* m, bool need_ln) {
     return m && m->w0 && m->b0 && m->w1 && m->b1 && (!need_ln || (m->ln_w && m->ln_b));

@@ -45,18 +45,30 @@ struct LinFwdArgs {
     int relu; float* out; long long rows;
 };
 
-template <bool TWO>
+// HALF: the product runs on the fp16 matrix pipe (two-term split, see mgn_device.h); otherwise fp32 MFMA.
+template <bool TWO, bool HALF>
 __global__ __launch_bounds__(NT, 2) void train_linear_fwd_kernel(LinFwdArgs a) {
     constexpr int K4 = TWO ? H / 2 : H / 4;
-    __shared__ __attribute__((aligned(16))) float X[tile_floats(K4)];
+    constexpr int KH = TWO ? 2 * H : H;              // columns of the staged tile
+    constexpr int LDH = KH + 8, PLN = TM * LDH;      // fp16 plane geometry
+    __shared__ __attribute__((aligned(16))) unsigned short Xs[HALF ? 2 * PLN : 2 * tile_floats(K4)];   // planes, or fp32 tile
     __shared__ __attribute__((aligned(16))) float O[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float vec[H];
+    float* X = (float*)Xs;
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
-    f32x4 wa[16], wb[TWO ? 16 : 1];
-    load_wfrag<16>(wa, a.W, a.ldw, a.koff_a, 32 * w + j, h);
-    if constexpr (TWO) load_wfrag<16>(wb, a.W, a.ldw, a.koff_b, 32 * w + j, h);
-    if (t < H) vec[t] = a.bias ? a.bias[t] : 0.f;
+    f32x4 wa[HALF ? 1 : 16], wb[(TWO && !HALF) ? 16 : 1];
+    WPlanesH<HALF ? 8 : 1> ha;
+    WPlanesH<(HALF && TWO) ? 8 : 1> hb;
+    if constexpr (HALF) {
+        load_wplanes_h<8>(ha, a.W, a.ldw, a.koff_a, 32 * w + j, h);
+        if constexpr (TWO) load_wplanes_h<8>(hb, a.W, a.ldw, a.koff_b, 32 * w + j, h);
+    } else {
+        load_wfrag<16>(wa, a.W, a.ldw, a.koff_a, 32 * w + j, h);
+        if constexpr (TWO) load_wfrag<16>(wb, a.W, a.ldw, a.koff_b, 32 * w + j, h);
+    }
+    constexpr float BS = HALF ? W_SCALE : 1.0f, US = HALF ? W_UNSCALE : 1.0f;
+    if (t < H) vec[t] = a.bias ? a.bias[t] * BS : 0.f;
     int t0, t1;
     tile_range(a.rows, t0, t1);
     const int srow = t >> 5, sq = t & 31;
@@ -68,13 +80,26 @@ __global__ __launch_bounds__(NT, 2) void train_linear_fwd_kernel(LinFwdArgs a) {
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it;
             const long long n = min(base + row, a.rows - 1);
-            *(f32x4*)(X + toff(row, sq, K4)) = *(const f32x4*)(a.A + n * H + 4 * sq);
-            if constexpr (TWO) *(f32x4*)(X + toff(row, 32 + sq, K4)) = *(const f32x4*)(a.B + n * H + 4 * sq);
+            const f32x4 va = *(const f32x4*)(a.A + n * H + 4 * sq);
+            if constexpr (HALF) hplanes_store4(Xs, PLN, LDH, row, 4 * sq, va);
+            else *(f32x4*)(X + toff(row, sq, K4)) = va;
+            if constexpr (TWO) {
+                const f32x4 vb = *(const f32x4*)(a.B + n * H + 4 * sq);
+                if constexpr (HALF) hplanes_store4(Xs, PLN, LDH, row, H + 4 * sq, vb);
+                else *(f32x4*)(X + toff(row, 32 + sq, K4)) = vb;
+            }
         }
         __syncthreads();
         f32x16 acc = acc_from_vec(vec, w, h);
-        acc = wave_gemm<16>(X, K4, 0, wa, j, h, acc);
-        if constexpr (TWO) acc = wave_gemm<16>(X, K4, 32, wb, j, h, acc);
+        if constexpr (HALF) {
+            acc = wave_gemm_h<0, 8, 8>(Xs, PLN, LDH, 0, ha, j, h, acc);
+            if constexpr (TWO) acc = wave_gemm_h<0, 8, 8>(Xs, PLN, LDH, H, hb, j, h, acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] *= US;
+        } else {
+            acc = wave_gemm<16>(X, K4, 0, wa, j, h, acc);
+            if constexpr (TWO) acc = wave_gemm<16>(X, K4, 32, wb, j, h, acc);
+        }
         if (a.P) {                                   // per-row gathered addends, accumulator layout
             const long long n = min(base + j, a.rows - 1);
             const size_t ip = (size_t)a.idxP[n] * H, iq = (size_t)a.idxQ[n] * H;
@@ -94,7 +119,7 @@ __global__ __launch_bounds__(NT, 2) void train_linear_fwd_kernel(LinFwdArgs a) {
             const int row = srow + 8 * it;
             if (row < nvalid) *(f32x4*)(a.out + (base + row) * H + 4 * sq) = *(const f32x4*)(O + toff(row, sq, H / 4));
         }
-        // X is restaged at the top of the next pass: every wave has finished its products before
+        // the tile is restaged at the top of the next pass: every wave has finished its products before
         // the barrier above; O is rewritten only after the next pass's first barrier
     }
 }
@@ -395,8 +420,15 @@ extern "C" int mgn_train_linear_fwd(const float* A, const float* B, const float*
     MGN_REQUIRE(ldw % 4 == 0 && koff_a % 4 == 0 && koff_b % 4 == 0, "mgn_train_linear_fwd");
     LinFwdArgs a{A, B, W, ldw, koff_a, koff_b, bias, P, idxP, Q, idxQ, relu, out, rows};
     const int g = train_grid(rows, 2);
-    if (B) hipLaunchKernelGGL((train_linear_fwd_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((train_linear_fwd_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    const bool half = mgn_matmul_mode() == 2;
+    hipStream_t s = (hipStream_t)stream;
+    if (B) {
+        if (half) hipLaunchKernelGGL((train_linear_fwd_kernel<true, true>), dim3(g), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((train_linear_fwd_kernel<true, false>), dim3(g), dim3(NT), 0, s, a);
+    } else {
+        if (half) hipLaunchKernelGGL((train_linear_fwd_kernel<false, true>), dim3(g), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((train_linear_fwd_kernel<false, false>), dim3(g), dim3(NT), 0, s, a);
+    }
     return check_launch("mgn_train_linear_fwd");
 }
 
