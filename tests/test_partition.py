@@ -52,6 +52,31 @@ def test_plan_invariants(world):
             assert np.array_equal(ids, exp)
 
 
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_interior_boundary_ranges(world):
+    """The receiver ranges used to overlap the halo exchange with compute: they tile the owned nodes,
+    their edge counts match the local CSR, and no interior receiver has an in-edge from a halo sender."""
+    g, ei, n, plans = _plans(20, 13, world)
+    for p in plans:
+        ls, lr = p.local_edge_index
+        rowptr = np.zeros(p.num_local + 1, dtype=np.int64)
+        np.cumsum(np.bincount(lr, minlength=p.num_local), out=rowptr[1:])
+        p._ranges(rowptr)
+        a, b, cnt = p.interior
+        pieces = sorted(p.boundary + [p.interior])
+        assert pieces[0][0] == 0 and pieces[-1][1] == p.num_owned
+        assert all(x[1] == y[0] for x, y in zip(pieces[:-1], pieces[1:]))
+        assert sum(x[2] for x in pieces) == ei[:, p.edge_ids].shape[1]
+        for n0, n1, c in pieces:
+            assert c == int(((lr >= n0) & (lr < n1)).sum())
+        inner = (lr >= a) & (lr < b)
+        assert np.all(ls[inner] < p.num_owned)
+        if world == 1:
+            assert (a, b) == (0, p.num_owned) and not p.boundary
+        elif world <= 3:
+            assert cnt > 0                              # strips several mesh rows high have interior receivers
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     return port
@@ -86,8 +111,10 @@ def _partitioned_forward(sd, cfg, norms, plan, gl):
         W1 = d(f"{p}.edge_mlp.0.weight")
         ps = torch.zeros(plan.num_local, H, dtype=torch.float64)
         ps[:n_own] = xh @ W1[:, :H].T
-        plan.exchange_rows(ps)                                    # halo rows arrive from their owners
+        pending = plan.exchange_rows(ps, async_op=True)           # halo rows arrive from their owners ...
         pr = xh @ W1[:, H:2 * H].T + d(f"{p}.edge_mlp.0.bias")
+        if pending is not None:
+            pending.wait()                                        # ... while other work proceeds
         h1 = F.relu(ps[s] + pr[r] + eh @ W1[:, 2 * H:].T)
         h2 = F.relu(F.linear(h1, d(f"{p}.edge_mlp.2.weight"), d(f"{p}.edge_mlp.2.bias")))
         en = F.layer_norm(h2, (H,), d(f"{p}.edge_mlp.4.weight"), d(f"{p}.edge_mlp.4.bias"), 1e-5)
