@@ -1149,14 +1149,16 @@ struct EncArgs {
 };
 
 // First Linear on the vector ALU (F <= 16 inputs, weights of 4 output features per thread in registers,
-// F4 = ceil(F / 4) input chunks), ReLU, hidden tile written as fp16 planes; second Linear on the fp16
-// matrix pipe (two-term split, W_SCALE folded into the LayerNorm epsilon); LayerNorm; coalesced store.
-// HALF = false keeps the second Linear on the fp32 matrix pipe (no fp16 range limit on the hidden values).
-template <int F4, bool HALF>
+// F4 = ceil(F / 4) input chunks), ReLU; second Linear on the matrix pipe; LayerNorm; coalesced store.
+// SPLIT = true: three-term bf16 split (six products).  The encoders are the one place where the
+// hidden values are not bounded by a LayerNorm upstream (a normalised input feature can be huge when
+// its training variance was tiny), so they never use the range-limited fp16 split.  SPLIT = false: fp32 MFMA.
+template <int F4, bool SPLIT>
 __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
+    constexpr bool HALF = SPLIT;                     // (name kept short below)
     constexpr int FP = 4 * F4;                       // padded input width
     __shared__ __attribute__((aligned(16))) float Fs[TM * FP];
-    __shared__ __attribute__((aligned(16))) unsigned short Hp[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];   // hidden tile: 2 fp16 planes, or fp32
+    __shared__ __attribute__((aligned(16))) unsigned short Hp[HALF ? 3 * PLANE : 2 * tile_floats(H / 4)];  // hidden tile: 3 bf16 planes, or fp32
     float* Hs = (float*)Hp;
     __shared__ __attribute__((aligned(16))) float Os[tile_floats(H / 4)];
     __shared__ __attribute__((aligned(16))) float vec[3][H];       // W_SCALE * b1, ln_w, ln_b
@@ -1165,11 +1167,11 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
     const int F = a.n_feat;
-    WPlanesH<HALF ? 8 : 1> wb;
+    WPlanes32 wb;
     f32x4 wf[HALF ? 1 : 16];
-    if constexpr (HALF) load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    if constexpr (HALF) load_wplanes32(wb, a.w1, H, 0, 32 * w + j, h);
     else load_wfrag<16>(wf, a.w1, H, 0, 32 * w + j, h);
-    constexpr float BS = HALF ? W_SCALE : 1.0f;      // scale carried by the second product
+    constexpr float BS = 1.0f;
     const int srow = t >> 5, sq = t & 31;
     // first-layer weights of features 4*sq .. 4*sq+3, zero padded to FP inputs
     float w0r[4][FP], b0r[4];
@@ -1210,12 +1212,12 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) hv[i] = fmaxf(hv[i], 0.f);
-            if constexpr (HALF) hplanes_store4(Hp, PLH, PKH, row, 4 * sq, hv);
+            if constexpr (HALF) planes_store4(Hp, row, 4 * sq, hv);
             else *(f32x4*)(Hs + toff(row, sq, H / 4)) = hv;
         }
         __syncthreads();
         f32x16 acc = acc_from_vec(vec[0], w, h);
-        if constexpr (HALF) acc = wave_gemm_h<0, 8, 8>(Hp, PLH, PKH, 0, wb, j, h, acc);
+        if constexpr (HALF) acc = wave_gemm3_32<0, 8>(Hp, wb, j, h, acc);
         else acc = wave_gemm<16>(Hs, H / 4, 0, wf, j, h, acc);
         ln_local_stats_rows(acc, red, w, j, h);
         __syncthreads();
@@ -1603,7 +1605,7 @@ extern "C" int mgn_encode(const float* feat, int32_t n_feat, const float* mean_s
     MGN_REQUIRE(feat && out && mlp_ok(enc, true), "mgn_encode");
     EncArgs a{feat, mean_std, enc->w0, enc->b0, enc->w1, enc->b1, enc->ln_w, enc->ln_b, out, (int)rows, (int)n_feat};
     const int g = grid_for((rows + TM - 1) / TM, 2);
-    const bool half = matmul_mode() == 2;
+    const bool half = matmul_mode() >= 1;            // bf16 split in both split modes (see encode_kernel)
     const int f4 = (n_feat + 3) / 4;
 #define MGN_LAUNCH_ENC(F4)                                                                                          \
     do {                                                                                                            \
