@@ -12,6 +12,8 @@
 // buffer and reduced by a second kernel in block order, so they are deterministic.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
+
 #include "mgn_device.h"
 
 namespace {
@@ -393,6 +395,26 @@ __global__ void loss_bwd_kernel(const float* __restrict__ dec, const float* __re
     }
 }
 
+// ------------------------------------------------------------------------ Adam over many tensors
+// One workgroup per table entry (a chunk of one parameter tensor): p, g, m, v pointers and a count.
+// torch.optim.Adam semantics (L2 weight decay added to the gradient, bias-corrected moments):
+//   g += wd * p;  m += (1 - b1) * (g - m);  v = b2 * v + (1 - b2) * g * g
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+struct AdamEntry { float* p; const float* g; float* m; float* v; long long n; };
+
+__global__ __launch_bounds__(NT) void adam_kernel(const AdamEntry* __restrict__ table, float step_size, float inv_sqrt_bc2,
+                                                  float b1, float b2, float eps, float wd) {
+    const AdamEntry e = table[blockIdx.x];
+    for (long long i = threadIdx.x; i < e.n; i += NT) {
+        const float p = e.p[i];
+        const float g = fmaf(wd, p, e.g[i]);
+        const float m = fmaf(1.0f - b1, g - e.m[i], e.m[i]);
+        const float v = fmaf(1.0f - b2, g * g, b2 * e.v[i]);
+        e.m[i] = m; e.v[i] = v;
+        e.p[i] = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    }
+}
+
 int train_grid(long long rows, int per_cu) { return grid_for((rows + TM - 1) / TM, per_cu); }
 
 int stream_grid(long long items, int per_block) {
@@ -523,4 +545,15 @@ extern "C" int mgn_train_loss_bwd(const float* decoded, const float* target_norm
     hipLaunchKernelGGL(loss_bwd_kernel, dim3(stream_grid(n_nodes * H, NT * 4)), dim3(NT), 0, (hipStream_t)stream, decoded,
                        target_norm, node_type, grad3, time_dim, (long long)n_nodes, gdecoded);
     return check_launch("mgn_train_loss_bwd");
+}
+
+extern "C" int mgn_adam_step(const void* table_dev, int32_t n_entries, float lr, float beta1, float beta2, float eps,
+                             float weight_decay, int64_t step, void* stream) {
+    MGN_REQUIRE(n_entries >= 0 && step >= 1, "mgn_adam_step");
+    if (n_entries == 0) return 0;
+    MGN_REQUIRE(table_dev && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "mgn_adam_step");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(n_entries), dim3(NT), 0, (hipStream_t)stream, (const AdamEntry*)table_dev,
+                       (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay);
+    return check_launch("mgn_adam_step");
 }

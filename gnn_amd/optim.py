@@ -1,0 +1,68 @@
+"""Adam on the HIP path: one kernel launch for all parameter tensors.
+
+Drop-in for the ``torch.optim.Adam(model.parameters(), lr=..., weight_decay=...)`` of
+run_train_multiscale.py:115-119 (same update rule, ``param_groups`` and ``state`` layout, so
+``CosineAnnealingLR`` (:122-126) and ``state_dict()`` work unchanged); ``amsgrad``, ``maximize`` and
+sparse gradients are not supported.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CHUNK = 1 << 14          # elements per workgroup
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
+            raise ValueError("FusedAdam: invalid hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            rows, dev, step = [], None, None
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU")
+                g = p.grad
+                if g.is_sparse or g.dtype != torch.float32 or g.device != p.device:
+                    raise RuntimeError("FusedAdam: gradients must be dense fp32 tensors on the parameter's device")
+                g = g if g.is_contiguous() else g.contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["step"] += 1
+                if step is None:
+                    step, dev = st["step"], p.device
+                elif st["step"] != step or p.device != dev:
+                    raise RuntimeError("FusedAdam: all parameters of a group must share step count and device")
+                n = p.numel()
+                for off in range(0, n, CHUNK):
+                    b = 4 * off
+                    rows.append((p.data_ptr() + b, g.data_ptr() + b, st["exp_avg"].data_ptr() + b,
+                                 st["exp_avg_sq"].data_ptr() + b, min(CHUNK, n - off)))
+            if not rows:
+                continue
+            # freed after the launch: the caching allocator hands memory back only to later work on this stream
+            table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev, non_blocking=False)
+            with torch.cuda.device(dev):
+                rc = _lib.lib().mgn_adam_step(C.c_void_p(table.data_ptr()), len(rows), float(group["lr"]),
+                                              float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                                              float(group["weight_decay"]), int(step),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _lib.check(rc, "mgn_adam_step")
+        return loss

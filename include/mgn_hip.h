@@ -219,6 +219,13 @@ int mgn_train_loss_fwd(const float* decoded, const float* target_norm, const flo
 int mgn_train_loss_bwd(const float* decoded, const float* target_norm, const float* node_type, const float* grad3,
                        int32_t time_dim, int64_t n_nodes, float* gdecoded, void* stream);
 
+/* One Adam step over many tensors in one launch: optimizer.step() of run_train_multiscale.py:115-119,
+ * :142 (torch.optim.Adam, amsgrad off: L2 weight decay added to the gradient, bias-corrected moments).
+ * table_dev: device array of n_entries records {float* param; const float* grad; float* exp_avg;
+ * float* exp_avg_sq; int64_t count} (40 bytes each), one workgroup per record; step counts from 1. */
+int mgn_adam_step(const void* table_dev, int32_t n_entries, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int64_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,7 +40,8 @@ def main():
     model = EncodeProcessDecodeMultiScale(10, 7, hidden_size=128, process_steps=args.mp_steps, coarse_process_steps=0,
                                           node_out_dim=3, attention=False, with_mat_params=False, sample_ratio=0.0,
                                           time_dim=1, device=dev).to(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5)
+    from gnn_amd.optim import FusedAdam
+    opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-5)
 
     def step(timers=None):
         t0 = time.perf_counter()
