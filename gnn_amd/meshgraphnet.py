@@ -291,6 +291,18 @@ class EncodeProcessDecodeMultiScale(nn.Module):
                        node_type=self._f32(graph["node_type"])[:n], pred=pred)
         return pred
 
+    def _normalized_target(self, graph) -> torch.Tensor:
+        """``output_normalizer(target - current state)`` [time_dim, N, 3], accumulating
+        (core/meshgraphnet.py:286-290)."""
+        target = self._f32(graph["target"])
+        cur = torch.cat([self._f32(graph["world_pos"]), self._f32(graph["phi"])], dim=-1)
+        halo = self.__dict__.get("halo")
+        if halo is None:
+            return self.output_normalizer(target - cur).contiguous()
+        n = halo.num_owned             # owned rows only; the statistics see the sums over all ranks
+        return self.output_normalizer((target[:, :n] - cur[:n]).contiguous(),
+                                      partial_sums_hook=halo.sum_hook("node")).contiguous()
+
     def loss(self, graph):
         """Masked squared error between the normalised target delta and the prediction
         (core/meshgraphnet.py:285-304): returns (total, ux, uy, phi).  The output normaliser
@@ -298,9 +310,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         of the HIP training kernels, so ``loss.backward()`` fills ``.grad`` of every parameter
         as run_train_multiscale.py:139-141 expects."""
         from . import training
-        target = self._f32(graph["target"])
-        cur = torch.cat([self._f32(graph["world_pos"]), self._f32(graph["phi"])], dim=-1)
-        tgt = self.output_normalizer(target - cur).contiguous()
+        tgt = self._normalized_target(graph)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             comps = training.loss_components(self, graph, tgt)
         else:

@@ -98,11 +98,12 @@ class Normalizer(nn.Module):
         return w["mean_std"]
 
     # ----------------------------------------------------------------- reference API
-    def forward(self, batched_data, accumulate=True):
-        """Normalizes input data and accumulates statistics (core/normalization.py:19-24)."""
+    def forward(self, batched_data, accumulate=True, partial_sums_hook=None):
+        """Normalizes input data and accumulates statistics (core/normalization.py:19-24).
+        ``partial_sums_hook`` as in :meth:`stats_for` (mesh-partitioned runs only)."""
         b, n, f = batched_data.shape
         rows = self._rows_view(batched_data.contiguous()).contiguous()
-        ms = self.stats_for(rows, accumulate)
+        ms = self.stats_for(rows, accumulate, partial_sums_hook)
         out = torch.empty_like(rows)
         ops.normalize(rows, ms, out, inverse=False)
         return out.reshape(n, b, f).permute(1, 0, 2).contiguous() if b > 1 else out.reshape(1, n, f)

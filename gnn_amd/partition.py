@@ -126,6 +126,46 @@ class HaloPlan:
                                       group=self.group, async_op=async_op)
         return work if async_op else buf
 
+    def return_rows(self, buf: torch.Tensor, async_op: bool = False):
+        """The reverse of :meth:`exchange_rows`, for gradients: the halo rows of ``buf``
+        [num_local, W] travel to their owners, which add them to their own rows (peer by peer in
+        rank order, so the result does not depend on timing).  Returns ``buf``, or with
+        ``async_op`` a handle whose ``wait()`` completes the addition (None when there is nothing
+        to do)."""
+        if self.world_size == 1:
+            return None if async_op else buf
+        send = buf[self.num_owned:].contiguous()
+        recv = buf.new_empty((int(self.send_idx.numel()), buf.shape[1]))
+        work = dist.all_to_all_single(recv, send, output_split_sizes=self.send_counts, input_split_sizes=self.recv_counts,
+                                      group=self.group, async_op=async_op)
+        plan = self
+
+        class _Pending:
+            def wait(self_inner):
+                if work is not None:
+                    work.wait()
+                plan._add_returned(buf, recv)
+
+        if async_op:
+            return _Pending()
+        self._add_returned(buf, recv)
+        return buf
+
+    def _add_returned(self, buf: torch.Tensor, recv: torch.Tensor) -> None:
+        off = 0
+        for q in range(self.world_size):          # ids are unique within one peer's list
+            cnt = self.send_counts[q]
+            if cnt:
+                ids = self.send_idx[off: off + cnt]
+                buf[ids] += recv[off: off + cnt]
+                off += cnt
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        """Sum over the ranks of the plan's group, in place."""
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
     def exchange_state(self, world_pos: torch.Tensor, phi: torch.Tensor):
         """Refreshes the halo rows of the per-step state (3 floats per halo node)."""
         if self.world_size == 1:
@@ -154,6 +194,22 @@ class HaloPlan:
         parts = [local_rows.new_empty((s,) + tuple(local_rows.shape[1:])) for s in sizes]
         dist.all_gather(parts, local_rows.contiguous(), group=self.group)
         return torch.cat(parts, dim=0)
+
+
+def all_reduce_gradients(model, group=None, average: bool = True) -> None:
+    """Data-parallel training over replicas (each rank a different trajectory): sums -- or averages --
+    the ``.grad`` of all parameters across the group with one all-reduce of one flat buffer."""
+    params = [p for p in model.parameters() if p.grad is not None]
+    if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat /= dist.get_world_size(group)
+    off = 0
+    for p in params:
+        p.grad.copy_(flat[off: off + p.numel()].view_as(p))
+        off += p.numel()
 
 
 def attach(model, plan: HaloPlan):

@@ -9,6 +9,7 @@ components out and the parameter gradients back; no arithmetic of the model runs
 """
 from __future__ import annotations
 
+import threading
 from typing import Dict, List
 
 import torch
@@ -22,11 +23,13 @@ def _empty(rows, dev):
 
 
 class _Scratch:
-    _by_dev: Dict[str, torch.Tensor] = {}
+    """Partial-sum buffer of the weight-gradient kernels: one per device and host thread (two
+    threads driving the same GPU must not share it)."""
+    _by_dev: Dict[tuple, torch.Tensor] = {}
 
     @classmethod
     def get(cls, dev) -> torch.Tensor:
-        key = str(dev)
+        key = (str(dev), threading.get_ident())
         buf = cls._by_dev.get(key)
         if buf is None:
             buf = torch.empty(ops.train_scratch_bytes(), dtype=torch.uint8, device=dev)
@@ -53,16 +56,16 @@ def _pad_rows(w: torch.Tensor, b: torch.Tensor):
 def forward_saving(model, graph, target_norm: torch.Tensor):
     """Runs the forward pass with the training kernels.  Returns (loss3 [3], saved) where
     ``saved`` holds what ``backward`` needs."""
-    if model.__dict__.get("halo") is not None:
-        raise NotImplementedError("training on a partitioned mesh is not implemented; train on one GPU per mesh")
+    halo = model.__dict__.get("halo")
     dev = graph["mesh_pos"].device
     if dev.type != "cuda":
         raise RuntimeError("the training kernels run on the GPU only")
     if model.node_out_dim != 3:
         raise RuntimeError("loss: node_out_dim must be 3")
     f32 = model._f32
-    topo = model.topology(graph)
-    n, e, T = topo.num_nodes, topo.num_edges, model.time_dim
+    topo = halo.topology if halo is not None else model.topology(graph)
+    n_loc, e, T = topo.num_nodes, topo.num_edges, model.time_dim
+    n = halo.num_owned if halo is not None else n_loc          # rows this rank computes; [n, n_loc) is the halo
     scratch = _Scratch.get(dev)
     node_f = model._node_feat_dim(graph)
     if node_f != model.node_encoder[0].weight.shape[1]:
@@ -70,14 +73,21 @@ def forward_saving(model, graph, target_norm: torch.Tensor):
 
     # features and normalisers (accumulating), as in the inference path
     world, mesh, phi = f32(graph["world_pos"]), f32(graph["mesh_pos"]), f32(graph["phi"])
-    node_type = f32(graph["node_type"])
+    node_type = f32(graph["node_type"])[:n].contiguous()
+    if halo is not None:
+        if mesh.shape[0] != n_loc:
+            raise RuntimeError(f"partitioned run: mesh_pos must hold the {n_loc} local rows [owned | halo]")
+        if world.shape[0] == n:                    # owned rows only: make room for the halo rows
+            world = torch.cat([world, world.new_empty(n_loc - n, 2)])
+            phi = torch.cat([phi, phi.new_empty(n_loc - n, 1)])
+        world, phi = halo.exchange_state(world, phi)
     mat = f32(graph["mat_param"]) if model.with_mat_params else None
     nfeat = torch.empty(n, node_f, dtype=torch.float32, device=dev)
     efeat = torch.empty(e, 7, dtype=torch.float32, device=dev)
-    ops.node_features(world, mesh, phi, f32(graph["swelling_phi"]), node_type, mat, nfeat)
+    ops.node_features(world[:n], mesh[:n], phi[:n], f32(graph["swelling_phi"])[:n], node_type, mat, nfeat)
     ops.edge_features(world, mesh, phi, topo.sender, topo.recv, efeat)
-    ms_n = model.node_features_normalizer.stats_for(nfeat, True, None)
-    ms_e = model.edge_features_normalizer.stats_for(efeat, True, None)
+    ms_n = model.node_features_normalizer.stats_for(nfeat, True, halo.sum_hook("node") if halo is not None else None)
+    ms_e = model.edge_features_normalizer.stats_for(efeat, True, halo.sum_hook("edge") if halo is not None else None)
     nf_pad, ef_pad = _empty(n, dev), _empty(e, dev)
     ops.train_pad_features(nfeat, ms_n, nf_pad)
     ops.train_pad_features(efeat, ms_e, ef_pad)
@@ -95,13 +105,18 @@ def forward_saving(model, graph, target_norm: torch.Tensor):
     el, enc_e = encoder(model.edge_encoder, ef_pad)
 
     layers: List[tuple] = []
-    ps, pr, eprime = _empty(n, dev), _empty(n, dev), _empty(e, dev)
+    ps, pr, eprime = _empty(n_loc, dev), _empty(n, dev), _empty(e, dev)
+    rowptr = topo.rowptr[: n + 1]                   # halo nodes receive nothing here: their rows stay with the owners
     blocks = list(model.processors)
     for i, blk in enumerate(blocks):
         em, nm = blk.edge_mlp, blk.node_mlp
         w0 = em[0].weight.detach()
-        ops.train_linear_fwd(x, w0, 0, ps)
+        ops.train_linear_fwd(x, w0, 0, ps[:n])
+        if halo is not None:
+            pending = halo.exchange_rows(ps, async_op=True)      # sender projections of the halo nodes
         ops.train_linear_fwd(x, w0, H, pr, bias=em[0].bias.detach())
+        if halo is not None and pending is not None:
+            pending.wait()
         h1e, ve = _empty(e, dev), _empty(e, dev)
         ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
         ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
@@ -110,7 +125,7 @@ def forward_saving(model, graph, target_norm: torch.Tensor):
         ops.train_ln_fwd(ve, em[4].weight.detach(), em[4].bias.detach(), y=eprime,
                          res=None if last else el, yres=e_next)
         aggr = _empty(n, dev)
-        ops.segment_sum(eprime, topo.rowptr, aggr)
+        ops.segment_sum(eprime, rowptr, aggr)
         h1n, vn, x_next = _empty(n, dev), _empty(n, dev), _empty(n, dev)
         ops.train_linear_fwd(x, nm[0].weight.detach(), 0, h1n, b=aggr, koff_b=H, bias=nm[0].bias.detach(), relu=True)
         ops.train_linear_fwd(h1n, nm[2].weight.detach(), 0, vn, bias=nm[2].bias.detach(), relu=True)
@@ -125,16 +140,19 @@ def forward_saving(model, graph, target_norm: torch.Tensor):
     ops.train_linear_fwd(hd, w2p, 0, decoded, bias=b2p)
     loss3 = torch.empty(3, dtype=torch.float32, device=dev)
     ops.train_loss_fwd(decoded, target_norm, node_type, T, loss3, scratch)
-    saved = dict(topo=topo, enc_n=enc_n, enc_e=enc_e, layers=layers, x_last=x, hd=hd, decoded=decoded, w2p=w2p,
+    if halo is not None:
+        halo.all_reduce_(loss3)                     # every term of the loss is a sum over nodes
+    saved = dict(topo=topo, halo=halo, enc_n=enc_n, enc_e=enc_e, layers=layers, x_last=x, hd=hd, decoded=decoded, w2p=w2p,
                  target_norm=target_norm, node_type=node_type)
     return loss3, saved
 
 
 def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
     """Gradients of ``sum_c grad3[c] * loss3[c]`` for every parameter, keyed like ``named_parameters``."""
-    topo = saved["topo"]
+    topo, halo = saved["topo"], saved["halo"]
     dev = grad3.device
-    n, e, T = topo.num_nodes, topo.num_edges, model.time_dim
+    n_loc, e, T = topo.num_nodes, topo.num_edges, model.time_dim
+    n = halo.num_owned if halo is not None else n_loc
     scratch = _Scratch.get(dev)
     grads: Dict[str, torch.Tensor] = {}
 
@@ -161,9 +179,12 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
 
     # ---- processor blocks in reverse
     ge = None                                     # gradient wrt the edge latents leaving the block
-    g2n, g1n, gaggr, dps, dpr = (_empty(n, dev) for _ in range(5))
+    g2n, g1n, gaggr, dpr = (_empty(n, dev) for _ in range(4))
+    dps_loc = _empty(n_loc, dev)
+    dps = dps_loc[:n]
     g2e, g1e = _empty(e, dev), _empty(e, dev)
     s_rowptr, s_order = topo.sender_view()
+    rowptr = topo.rowptr[: n + 1]
     blocks = list(model.processors)
     for i in range(len(blocks) - 1, -1, -1):
         blk, pre = blocks[i], f"processors.{i}."
@@ -196,8 +217,12 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
         else:
             ops.train_linear_bwd(g1e, scratch, a=el, w=w_e0, koff=2 * H, res=ge, ga=ge, dw=dw0, dw_koff=2 * H)
         # per-node projections: ps = x W0s^T (sender side), pr = x W0r^T + b0 (receiver side)
-        ops.segment_sum(g1e, topo.rowptr, dpr)
-        ops.segment_sum(g1e, s_rowptr, dps, order=s_order)
+        ops.segment_sum(g1e, s_rowptr, dps_loc, order=s_order)
+        if halo is not None:
+            pending = halo.return_rows(dps_loc, async_op=True)   # halo senders' sums go back to their owners
+        ops.segment_sum(g1e, rowptr, dpr)
+        if halo is not None and pending is not None:
+            pending.wait()
         ops.train_linear_bwd(dps, scratch, a=x, w=w_e0, koff=0, res=gx, ga=gx, dw=dw0, dw_koff=0)
         ops.train_linear_bwd(dpr, scratch, a=x, w=w_e0, koff=H, res=gx, ga=gx, dw=dw0, dw_koff=H, db=db0)
         grads[pre + "edge_mlp.0.weight"], grads[pre + "edge_mlp.0.bias"] = dw0, db0
@@ -220,6 +245,14 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
     if ge is None:                                # no processor blocks: the edge encoder does not reach the loss
         ge = torch.zeros(e, H, dtype=torch.float32, device=dev)
     encoder_bwd(model.edge_encoder, "edge_encoder", saved["enc_e"], ge, g2e, g1e)
+    if halo is not None:
+        # each rank holds the sums over its own rows: one all-reduce over all 136 tensors (4.84 MB)
+        flat = torch.cat([g.reshape(-1) for g in grads.values()])
+        halo.all_reduce_(flat)
+        off = 0
+        for k, g in grads.items():
+            grads[k] = flat[off: off + g.numel()].view_as(g)
+            off += g.numel()
     return grads
 
 

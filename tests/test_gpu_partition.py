@@ -55,6 +55,39 @@ def _thread_plan(ei, n, world, rank, bus):
             buf[plan.num_owned:].fill_(float("nan"))      # stale halo rows must not be read before wait()
             return Pending()
 
+        def return_rows(self, buf, async_op=False):
+            plan = self
+
+            def run():
+                bus.slots[plan.rank] = (buf[plan.num_owned:].clone(), plan.recv_counts)
+                bus.barrier.wait()
+                got = []
+                for q in range(plan.world_size):
+                    if q == plan.rank:
+                        continue
+                    s, counts = bus.slots[q]                 # q's halo rows, grouped by owner
+                    start, cnt = sum(counts[: plan.rank]), counts[plan.rank]
+                    got.append(s[start: start + cnt])
+                bus.barrier.wait()
+                plan._add_returned(buf, torch.cat(got) if got else buf.new_empty((0, buf.shape[1])))
+
+            if not async_op:
+                run()
+                return buf
+
+            class Pending:
+                def wait(self_inner):
+                    run()
+            return Pending()
+
+        def all_reduce_(self, t):
+            bus.slots[self.rank] = t.clone()
+            bus.barrier.wait()
+            tot = torch.stack([bus.slots[q] for q in range(self.world_size)]).sum(0)
+            bus.barrier.wait()
+            t.copy_(tot)
+            return t
+
         def sum_hook(self, kind):
             total = self.global_nodes if kind == "node" else self.global_edges
 
@@ -115,3 +148,57 @@ def test_partitioned_rollout_matches_single_gpu(world):
     # the float64 normaliser partial sums are added in a different grouping than on one GPU,
     # which can move the fp32 statistics by one ulp; everything else is bit-identical
     assert rel_l2(out, ref) < 1e-6, rel_l2(out, ref)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_partitioned_training_step_matches_single_gpu(world):
+    """loss + backward on a mesh split over ranks: forward halo of the sender projections, reverse
+    halo of their gradients, one all-reduce of the loss and of the parameter gradients.  Every rank
+    must end with the single-GPU loss and gradients (sums are grouped differently: 1e-5)."""
+    from gnn_amd import partition
+    from gnn_amd.graph import MeshGraph
+    from test_gpu_model import build_model
+    cfg = O.OracleConfig(process_steps=3)
+    sd = O.init_state_dict(cfg, 11)
+    g = O.synthetic_graph(40, 33, seed=8)
+    n = g["mesh_pos"].shape[0]
+    gen = torch.Generator().manual_seed(2)
+    g["target"] = (torch.cat([g["world_pos"], g["phi"]], dim=-1)
+                   + 0.01 * torch.randn(cfg.time_dim, n, 3, generator=gen))
+
+    def loss_and_grads(model, graph):
+        # what loss() + backward() run, called directly: torch's autograd engine would run the
+        # backward of all "ranks" on its one worker thread for the device, where the in-process
+        # exchanges of this test would wait for each other for ever
+        from gnn_amd import training
+        tgt = model._normalized_target(graph)
+        loss3, saved = training.forward_saving(model, graph, tgt)
+        grads = training.backward(model, saved, torch.ones(3, device=DEV))
+        return loss3.clone(), {k: v.clone() for k, v in grads.items()}
+
+    ref_model = build_model(cfg, sd)
+    ref_loss, ref_grads = loss_and_grads(ref_model, MeshGraph(**g).to(DEV))
+
+    bus = _Bus(world)
+    results, errors = [None] * world, []
+
+    def worker(rank):
+        try:
+            torch.cuda.set_device(0)
+            plan = _thread_plan(g["edge_index"].numpy(), n, world, rank, bus)
+            model = partition.attach(build_model(cfg, sd), plan)
+            gl = plan.local_graph(MeshGraph(**g)).to(DEV)
+            results[rank] = loss_and_grads(model, gl) + (model.output_normalizer._acc_count,)
+        except Exception as exc:          # noqa: BLE001
+            errors.append(exc)
+            bus.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+    [t.start() for t in threads]
+    [t.join(timeout=100) for t in threads]
+    assert not errors, errors
+    for loss, grads, count in results:
+        assert count == ref_model.output_normalizer._acc_count
+        assert rel_l2(loss, ref_loss) < 1e-5, rel_l2(loss, ref_loss)
+        worst = max(rel_l2(grads[k], ref_grads[k]) for k in ref_grads)
+        assert worst < 1e-5, worst

@@ -149,7 +149,30 @@ def _worker(rank, world, port, ret):
         norms = O.make_norms(cfg)
         local = _partitioned_forward(sd, cfg, norms, plan, gl)
         full = plan.gather_owned(local.permute(1, 0, 2).contiguous()).permute(1, 0, 2)
+        # reverse exchange: every rank contributes a value per local node (owned and halo); after
+        # return_rows the owners hold the sum over all ranks that reference the node
+        contrib = torch.from_numpy(plan.local_node_ids).double().reshape(-1, 1) * torch.tensor([[1.0, 0.5]], dtype=torch.float64)
+        contrib = contrib * (rank + 1)
+        pend = plan.return_rows(contrib, async_op=True)
+        if pend is not None:
+            pend.wait()
+        summed = plan.gather_owned(contrib[: plan.num_owned].contiguous())
+        tot = plan.all_reduce_(torch.tensor([float(rank + 1)]))
+        from gnn_amd.partition import all_reduce_gradients
+        lin = torch.nn.Linear(3, 2)
+        for prm in lin.parameters():
+            prm.grad = torch.full_like(prm, float(rank + 1))
+        all_reduce_gradients(lin)                                 # replicas: averaged gradients
+        avg_ok = all(torch.equal(prm.grad, torch.full_like(prm, (world + 1) / 2)) for prm in lin.parameters())
         if rank == 0:
+            ret["avg_ok"] = avg_ok
+            expect = torch.zeros(n, 2, dtype=torch.float64)
+            for q in range(world):
+                pq = HaloPlan(g["edge_index"].numpy(), n, world, q)
+                ids = torch.from_numpy(pq.local_node_ids)
+                expect[ids] += ids.double().reshape(-1, 1) * torch.tensor([[1.0, 0.5]], dtype=torch.float64) * (q + 1)
+            ret["return_rows_ok"] = bool(torch.equal(summed, expect))
+            ret["all_reduce_ok"] = float(tot) == sum(range(1, world + 1))
             ref_norms = O.make_norms(cfg)
             with torch.no_grad():
                 ref = O.forward(sd, cfg, ref_norms, g)
@@ -167,5 +190,6 @@ def test_two_rank_halo_exchange_matches_full_mesh():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["count_ok"]
+    assert ret["return_rows_ok"] and ret["all_reduce_ok"] and ret["avg_ok"]
     assert ret["sum_rel"] < 1e-6
     assert ret["rel"] < 2e-5, ret["rel"]
