@@ -1434,6 +1434,23 @@ __global__ void normalize_kernel(const float* __restrict__ x, const float* __res
     }
 }
 
+// Training-noise injection of one frame (core/datasetclass.py:75-89): z * level * scale added to
+// the state, except on Dirichlet nodes.  Unfused multiplies and adds, in the reference's order.
+__global__ void inject_noise_kernel(const float* __restrict__ world, const float* __restrict__ phi,
+                                    const float* __restrict__ node_type, const float* __restrict__ zw,
+                                    const float* __restrict__ zp, float level, float conn, float phi_range,
+                                    float* __restrict__ out_world, float* __restrict__ out_phi, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float* nt = node_type + (size_t)i * 5;
+        const float nx = nt[1] == 1.f ? 0.f : __fmul_rn(__fmul_rn(zw[2 * i], level), conn);
+        const float ny = nt[2] == 1.f ? 0.f : __fmul_rn(__fmul_rn(zw[2 * i + 1], level), conn);
+        const float np = nt[3] == 1.f ? 0.f : __fmul_rn(__fmul_rn(zp[i], level), phi_range);
+        out_world[2 * i] = __fadd_rn(world[2 * i], nx);
+        out_world[2 * i + 1] = __fadd_rn(world[2 * i + 1], ny);
+        out_phi[i] = __fadd_rn(phi[i], np);
+    }
+}
+
 __global__ void gather_rows_kernel(const float* __restrict__ src, const long long* __restrict__ idx,
                                    float* __restrict__ dst, long long rows, int w4, bool scatter) {
     const long long total = rows * w4;
@@ -1643,6 +1660,18 @@ extern "C" int mgn_normalize(const float* x, const float* mean_std, float* out, 
     hipLaunchKernelGGL(normalize_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, x, mean_std, out,
                        (long long)total, (int)n_feat, inverse != 0);
     return check_launch("mgn_normalize");
+}
+
+extern "C" int mgn_inject_noise(const float* world_pos, const float* phi, const float* node_type, const float* z_world,
+                                const float* z_phi, float level, float conn_length, float phi_range, float* out_world,
+                                float* out_phi, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (int64_t)1 << 30, "mgn_inject_noise");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(world_pos && phi && node_type && z_world && z_phi && out_world && out_phi, "mgn_inject_noise");
+    const int g = (int)std::min<int64_t>((n_nodes + NT - 1) / NT, 16384);
+    hipLaunchKernelGGL(inject_noise_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, world_pos, phi, node_type, z_world,
+                       z_phi, level, conn_length, phi_range, out_world, out_phi, (int)n_nodes);
+    return check_launch("mgn_inject_noise");
 }
 
 static int rows_copy(const float* src, const int64_t* idx, float* dst, int64_t rows, int32_t width, void* stream,

@@ -73,6 +73,76 @@ def synthetic_frames(nx: int, ny: int, n_frames: int = 1, seed: int = 0, lx: flo
     return frames
 
 
+class DeviceTrajectory:
+    """One trajectory resident on the GPU; frames are views of it.
+
+    The reference builds T python frames per ``__getitem__`` on the host and the training loop
+    moves each of them to the device (core/datasetclass.py:43-108, run_train_multiscale.py:137-138).
+    Here the ``[T, N, .]`` series are uploaded once; ``frame(t)`` returns the fields of the
+    reference's frame t (:97-106) as device tensors -- target and state are slices of the resident
+    series, the noise (:75-89) is injected by ``mgn_inject_noise`` from device-side normal draws --
+    so a training step does no host-to-device copy.  ``edge_index`` is one tensor for all frames,
+    hence one cached topology."""
+
+    def __init__(self, sample, device, time_dim: int = 1):
+        """``sample``: mapping with the ``.npz`` schema of the reference's generators
+        (bending_gen.py:297-306) -- a loaded ``.npz`` or a dict of arrays."""
+        f32 = lambda k: torch.as_tensor(np.asarray(sample[k]), dtype=torch.float32)
+        self.device, self.time_dim = torch.device(device), int(time_dim)
+        mesh_pos = f32("mesh_coords")
+        cells = torch.as_tensor(np.asarray(sample["cells"]), dtype=torch.long)
+        edge_index = cells_to_edge_index(cells)
+        node_type = f32("node_type")
+        world = mesh_pos + f32("u_time_series")
+        phi = f32("φ_time_series").unsqueeze(-1)
+        swell = f32("swell_time_series").reshape(-1, 1)
+        swell_nodes = node_type[:, 4] == 1
+        swell_full = torch.zeros(phi.shape[0], phi.shape[1])
+        swell_full[:, swell_nodes] = swell.expand(phi.shape[0], int(swell_nodes.sum()))
+        row, col = edge_index
+        # scales of the noise model, constants of the trajectory (core/datasetclass.py:76, :83)
+        self.conn_length = float(torch.max(torch.norm(mesh_pos[row] - mesh_pos[col], dim=-1))) if edge_index.numel() else 0.0
+        self.phi_range = float(torch.max(phi) - torch.min(phi))
+        dev = self.device
+        self.mesh_pos, self.node_type, self.cells = mesh_pos.to(dev), node_type.to(dev), cells.to(dev)
+        self.edge_index = edge_index.to(dev)
+        self.mat_param = torch.tensor([np.asarray(sample["chi"]).item(), np.asarray(sample["diffusivity"]).item()],
+                                      dtype=torch.float32, device=dev)
+        self.time = f32("t").to(dev)
+        self.world_pos, self.phi = world.to(dev), phi.to(dev)                  # [T, N, 2], [T, N, 1]
+        self.state = torch.cat([self.world_pos, self.phi], dim=-1)             # [T, N, 3]: targets are slices of it
+        self.swelling = swell_full.T.contiguous().to(dev)                      # [N, T]
+        self.num_steps = world.shape[0]
+
+    def __len__(self):
+        """Number of training frames (those with ``time_dim`` successors, core/datasetclass.py:66-72)."""
+        return self.num_steps - self.time_dim
+
+    def frame(self, t: int, noise_level: float = 0.0, generator=None, with_target: bool = True) -> MeshGraph:
+        td = self.time_dim
+        if not 0 <= t < (len(self) if with_target else self.num_steps):
+            raise IndexError(f"frame {t} out of range")
+        world, phi = self.world_pos[t], self.phi[t]
+        if noise_level and noise_level > 0.0:
+            n = world.shape[0]
+            zw = torch.randn(n, 2, device=self.device, generator=generator)
+            zp = torch.randn(n, 1, device=self.device, generator=generator)
+            nw, nphi = torch.empty_like(world), torch.empty_like(phi)
+            ops.inject_noise(world, phi, self.node_type, zw, zp, noise_level, self.conn_length, self.phi_range, nw, nphi)
+            world, phi = nw, nphi
+        g = MeshGraph(mesh_pos=self.mesh_pos, node_type=self.node_type, mat_param=self.mat_param, cells=self.cells,
+                      edge_index=self.edge_index, time=self.time[t], world_pos=world, phi=phi)
+        if with_target:
+            g["swelling_phi"] = self.swelling[:, t: t + td + 1].contiguous()    # [N, time_dim + 1]
+            g["target"] = self.state[t + 1: t + 1 + td]                         # [time_dim, N, 3]
+        else:
+            g["swelling_phi"] = self.swelling[:, t].contiguous()
+        return g
+
+    def frames(self, noise_level: float = 0.0, generator=None):
+        return [self.frame(t, noise_level, generator) for t in range(len(self))]
+
+
 class HydrogelDataset(torch.utils.data.Dataset):
     """``.npz`` trajectories -> lists of frames (core/datasetclass.py:22-119): same constructor
     arguments, same fields per frame, same noise model (:75-89) and multi-step targets (:66-72)."""
@@ -90,6 +160,10 @@ class HydrogelDataset(torch.utils.data.Dataset):
 
     def get_name(self, idx):
         return self.data_files[idx].rstrip(".npz")
+
+    def device_trajectory(self, idx, device) -> DeviceTrajectory:
+        """Trajectory ``idx`` uploaded once; its ``frame(t, noise_level)`` replaces the host frames."""
+        return DeviceTrajectory(np.load(os.path.join(self.data_dir, self.data_files[idx])), device, self.time_dim)
 
     def __getitem__(self, idx):
         s = np.load(os.path.join(self.data_dir, self.data_files[idx]))

@@ -234,6 +234,17 @@ def normalize(x2d, mean_std, out, inverse: bool = False):
     _lib.check(rc, "mgn_normalize")
 
 
+def inject_noise(world_pos, phi, node_type, z_world, z_phi, level, conn_length, phi_range, out_world, out_phi):
+    n = world_pos.shape[0]
+    rc = _lib.lib().mgn_inject_noise(_dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(phi, torch.float32, (n, 1), "phi"),
+                                     _dev(node_type, torch.float32, (n, 5), "node_type"),
+                                     _dev(z_world, torch.float32, (n, 2), "z_world"), _dev(z_phi, torch.float32, (n, 1), "z_phi"),
+                                     float(level), float(conn_length), float(phi_range),
+                                     _dev(out_world, torch.float32, (n, 2), "out_world"),
+                                     _dev(out_phi, torch.float32, (n, 1), "out_phi"), n, _stream())
+    _lib.check(rc, "mgn_inject_noise")
+
+
 def encode(feat, mean_std, mlp: MlpWeights, out):
     m, f = feat.shape
     if f > MAX_FEAT or mlp.in_dim != f or mlp.out_dim != H:

@@ -12,7 +12,12 @@ import torch
 from .graph import MeshGraph, batch_graphs, unbatch_nodes
 
 
-def rollout(model, data, progress: bool = False):
+def rollout(model, data, progress: bool = False, reorder=None):
+    """``reorder``: None, or "rcm" / "morton" to renumber the nodes for locality before the
+    first step (meshes whose ids do not follow the geometry); every returned tensor stays in
+    the order of ``data``."""
+    if reorder is not None:
+        return _rollout_reordered(model, data, progress, reorder)
     device = model.device
     time_dim = model.time_dim
     n_frames = len(data)
@@ -59,6 +64,18 @@ def rollout(model, data, progress: bool = False):
         "rmse_y": rmse_y,
         "rmse_phi": rmse_phi,
     }
+
+
+def _rollout_reordered(model, data, progress, method):
+    from . import reorder as R
+    order = R.node_order(data[0], method)
+    edges = R.permute_frame({"mesh_pos": data[0]["mesh_pos"], "edge_index": data[0]["edge_index"]}, order)["edge_index"]
+    res = rollout(model, [R.permute_frame(fr, order, relabelled_edges=edges) for fr in data], progress)
+    for k in ("pred", "gt", "swelling_phi"):
+        res[k] = R.restore_nodes(res[k], order, dim=1)
+    first = data[0]
+    res.update(mesh_pos=first["mesh_pos"], cells=first["cells"], node_type=first["node_type"])
+    return res
 
 
 def rollout_batched(model, trajectories, progress: bool = False):

@@ -136,6 +136,16 @@ int mgn_norm_update(float* acc_sum, float* acc_sumsq, const double* sums, int32_
 int mgn_normalize(const float* x, const float* mean_std /*[2F]*/, float* out, int64_t rows, int32_t n_feat,
                   int32_t inverse, void* stream);
 
+/* Training-noise injection of one frame (core/datasetclass.py:75-89), on the device:
+ * out_world = world_pos + z_world * level * conn_length with the x (y) component left alone
+ * where node_type[:,1] (node_type[:,2]) == 1; out_phi = phi + z_phi * level * phi_range except
+ * where node_type[:,3] == 1.  z_* are the caller's standard-normal draws ([N,2] and [N]);
+ * conn_length is the longest mesh edge (:76), phi_range = max(phi) - min(phi) over the whole
+ * trajectory (:83).  Products and sums are rounded one by one, in the reference's order. */
+int mgn_inject_noise(const float* world_pos /*[N,2]*/, const float* phi /*[N]*/, const float* node_type /*[N,5]*/,
+                     const float* z_world /*[N,2]*/, const float* z_phi /*[N]*/, float level, float conn_length,
+                     float phi_range, float* out_world /*[N,2]*/, float* out_phi /*[N]*/, int64_t n_nodes, void* stream);
+
 /* Encoder (core/meshgraphnet.py:137-138, :177-178): out = LN(W1 ReLU(W0 z + b0) + b1),
  * z = (feat - mean) / std  (Normalizer.forward, core/normalization.py:24).  mean_std may
  * be NULL for z = feat.  n_feat <= MGN_MAX_FEAT.                                      */

@@ -33,7 +33,7 @@ __all__ = [
     "OracleConfig", "NormStats", "cells_to_edge_index", "receiver_csr", "grid_mesh",
     "init_state_dict", "mlp", "mp_layer", "mp_layer_csr_projected", "node_features",
     "edge_features", "forward", "predict", "loss", "rollout", "make_norms",
-    "synthetic_graph", "bending_node_type", "state_dict_digest", "forced_relu_masks",
+    "synthetic_graph", "bending_node_type", "state_dict_digest", "forced_relu_masks", "inject_noise",
 ]
 
 
@@ -373,6 +373,16 @@ def rollout(sd, cfg: OracleConfig, norms: Dict[str, NormStats], static, world_po
 
 
 # --------------------------------------------------------------------------- synthetic inputs
+def inject_noise(world_pos, phi, node_type, z_world, z_phi, level: float, conn_length, phi_range):
+    """Training noise of one frame with the standard-normal draws given (core/datasetclass.py:75-89)."""
+    wn = z_world * level * conn_length
+    wn[node_type[:, 1] == 1, 0] = 0.0
+    wn[node_type[:, 2] == 1, 1] = 0.0
+    pn = z_phi * level * phi_range
+    pn[node_type[:, 3] == 1] = 0.0
+    return world_pos + wn, phi + pn
+
+
 def bending_node_type(nx: int, ny: int) -> np.ndarray:
     """Five indicator columns in the layout of gt_gen/gt_gen/bending_gen.py:11-16, :317-322:
     column 0 free, 1 ux fixed, 2 uy fixed, 3 phi fixed, 4 swelling boundary.  Left column of
