@@ -195,87 +195,6 @@ __device__ unsigned long long g_stamps[2][16];
 #define STAMP_FLUSH(slot)
 #endif
 
-// ======================================================================== split-bf16 matrix path
-// fp32 products on the bf16 matrix pipe.  Every fp32 operand is cut EXACTLY into three bf16
-// terms by truncation (8 + 8 + 8 significant bits: x = hi + mid + lo, no rounding anywhere),
-// and a product x*w is evaluated as the six partial products whose weight is >= 2^-16 of it:
-//   hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi        (dropped: mid*lo, lo*mid, lo*lo < 2^-23)
-// accumulated in fp32 by v_mfma_f32_32x32x16_bf16, smallest terms first.  Unlike the fp32 MFMA, the
-// bf16 MFMA runs beside vector-ALU work of another wave on the same SIMD, and the six products
-// cost 6/16 of the fp32 matrix time.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int PK = H + 8;                          // bf16 per plane row: 256 B of data + 16 B pad
-constexpr int PLANE = TM * PK;                     // bf16 per plane of a 32-row tile
-
-// x = hi + mid + lo (exact); returns the three terms as fp32 bit patterns with 16 low zero bits
-__device__ __forceinline__ void split3(float x, unsigned& hi, unsigned& mid, unsigned& lo) {
-    hi = __float_as_uint(x) & 0xFFFF0000u;
-    const float r1 = x - __uint_as_float(hi);
-    mid = __float_as_uint(r1) & 0xFFFF0000u;
-    lo = __float_as_uint(r1 - __uint_as_float(mid));          // at most 8 significant bits are left
-}
-// two bf16 (upper halves of a and b) in one dword, a in the low half
-__device__ __forceinline__ unsigned pack_hi16(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
-
-// four consecutive fp32 -> per plane two dwords (4 bf16)
-__device__ __forceinline__ void split_pack4(const f32x4 v, u32x2& ph, u32x2& pm, u32x2& pl) {
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) split3(v[i], h[i], m[i], l[i]);
-    ph = u32x2{pack_hi16(h[0], h[1]), pack_hi16(h[2], h[3])};
-    pm = u32x2{pack_hi16(m[0], m[1]), pack_hi16(m[2], m[3])};
-    pl = u32x2{pack_hi16(l[0], l[1]), pack_hi16(l[2], l[3])};
-}
-
-// write 4 consecutive features of one tile row as three bf16 planes
-__device__ __forceinline__ void planes_store4(unsigned short* tile, int row, int k, const f32x4 v) {
-    u32x2 ph, pm, pl;
-    split_pack4(v, ph, pm, pl);
-    unsigned short* d = tile + row * PK + k;
-    *(u32x2*)(d) = ph; *(u32x2*)(d + PLANE) = pm; *(u32x2*)(d + 2 * PLANE) = pl;
-}
-
-// Register-resident weight planes of one 128-wide Linear for the 32 output features of a wave
-// (v_mfma_f32_32x32x16_bf16: lane (i = lane & 31, h = lane >> 5) feeds k = 16c + 8h + 0..7).
-struct WPlanes32 { u32x4 p[3][8]; };
-
-__device__ __forceinline__ void load_wplanes32(WPlanes32& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
-    const float* row = W + (size_t)feat * ldw + koff + 8 * h;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const f32x4 lo4 = *(const f32x4*)(row + 16 * c), hi4 = *(const f32x4*)(row + 16 * c + 4);
-        u32x2 a[3], b[3];
-        split_pack4(lo4, a[0], a[1], a[2]);
-        split_pack4(hi4, b[0], b[1], b[2]);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) w.p[p][c] = u32x4{a[p][0], a[p][1], b[p][0], b[p][1]};
-    }
-}
-
-__device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-// acc[32 feats][32 rows] += W * planes^T over k-steps [C0, C1) of 16; `tile` = plane 0 of a
-// [3][TM][PK] bf16 image; lane (j = lane & 31, h = lane >> 5).  Smallest partial products first.
-template <int C0, int C1>
-__device__ __forceinline__ f32x16 wave_gemm3_32(const unsigned short* tile, const WPlanes32& w, int j, int h, f32x16 acc) {
-    const unsigned short* r = tile + j * PK + 8 * h;
-#pragma unroll
-    for (int c = C0; c < C1; ++c) {
-        const u32x4 xh = *(const u32x4*)(r + 16 * c), xm = *(const u32x4*)(r + PLANE + 16 * c),
-                    xl = *(const u32x4*)(r + 2 * PLANE + 16 * c);
-        acc = mfma32_bf16(w.p[2][c], xh, acc);   // lo * hi
-        acc = mfma32_bf16(w.p[0][c], xl, acc);   // hi * lo
-        acc = mfma32_bf16(w.p[1][c], xm, acc);   // mid * mid
-        acc = mfma32_bf16(w.p[1][c], xh, acc);   // mid * hi
-        acc = mfma32_bf16(w.p[0][c], xm, acc);   // hi * mid
-        acc = mfma32_bf16(w.p[0][c], xh, acc);   // hi * hi
-    }
-    return acc;
-}
-
 constexpr int PKH = H + 8;          // halves per plane row of a 128-column tile
 constexpr int NT3 = 512;
 

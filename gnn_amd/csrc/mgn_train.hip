@@ -288,6 +288,186 @@ __global__ __launch_bounds__(NT, 2) void train_linear_bwd_kernel(LinBwdArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------ linear backward, split-bf16 path
+// Same contract as train_linear_bwd_kernel with both products on the bf16 matrix pipe (three exact
+// bf16 terms per fp32 operand, six partial products; gradients keep their full exponent range).
+//   GA = G W      : contraction over the Linear's outputs f; G tile as row-major planes, W^T in registers.
+//   dW = G^T A    : contraction over the 32 rows of the tile; both tiles as TRANSPOSED planes
+//                   (feature-major, 8 consecutive rows = one 16-byte operand fragment).
+// One workgroup per CU (the LDS images of a tile take 104 KB); the next tile's rows are loaded into
+// registers while the current tile's products run.
+constexpr int TK = TM + 8;                  // halves per feature row of a transposed plane (64 B + 16 B pad)
+constexpr int TPLANE = H * TK;              // halves per transposed plane
+
+// halves offset of rows 8*blk .. 8*blk+7 of feature f; the four 16-byte blocks of a feature row are
+// permuted by bits 4-5 of f so that the transposing stores of a wave spread over the LDS banks
+__device__ __forceinline__ int tpos(int f, int blk) { return f * TK + 8 * (blk ^ ((f >> 4) & 3)); }
+
+// rows r0, r0+1 (r0 even) x features k..k+3: transposed planes, and optionally the row-major planes
+template <bool ROWMAJOR, bool TRANSPOSED>
+__device__ __forceinline__ void stage_rows2(unsigned short* rm, unsigned short* tp, int r0, int k, const f32x4 v0, const f32x4 v1) {
+    unsigned h0[4], m0[4], l0[4], h1[4], m1[4], l1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { split3(v0[c], h0[c], m0[c], l0[c]); split3(v1[c], h1[c], m1[c], l1[c]); }
+    if constexpr (ROWMAJOR) {
+        unsigned short* d0 = rm + r0 * PK + k;
+        unsigned short* d1 = d0 + PK;
+        *(u32x2*)(d0) = u32x2{pack_hi16(h0[0], h0[1]), pack_hi16(h0[2], h0[3])};
+        *(u32x2*)(d0 + PLANE) = u32x2{pack_hi16(m0[0], m0[1]), pack_hi16(m0[2], m0[3])};
+        *(u32x2*)(d0 + 2 * PLANE) = u32x2{pack_hi16(l0[0], l0[1]), pack_hi16(l0[2], l0[3])};
+        *(u32x2*)(d1) = u32x2{pack_hi16(h1[0], h1[1]), pack_hi16(h1[2], h1[3])};
+        *(u32x2*)(d1 + PLANE) = u32x2{pack_hi16(m1[0], m1[1]), pack_hi16(m1[2], m1[3])};
+        *(u32x2*)(d1 + 2 * PLANE) = u32x2{pack_hi16(l1[0], l1[1]), pack_hi16(l1[2], l1[3])};
+    }
+    if constexpr (TRANSPOSED) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned* d = (unsigned*)(tp + tpos(k + c, r0 >> 3) + (r0 & 7));
+            d[0] = pack_hi16(h0[c], h1[c]);
+            d[TPLANE / 2] = pack_hi16(m0[c], m1[c]);
+            d[TPLANE] = pack_hi16(l0[c], l1[c]);
+        }
+    }
+}
+
+// W^T planes for output column `col` of GA: k-step c covers the Linear's outputs f = 16c + 8h + 0..7
+__device__ __forceinline__ void load_wplanes32_t(WPlanes32& w, const float* __restrict__ W, int ldw, int col, int h) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float* p = W + (size_t)(16 * c + 8 * h) * ldw + col;
+        const size_t l = (size_t)ldw;
+        const f32x4 lo4 = {p[0], p[l], p[2 * l], p[3 * l]}, hi4 = {p[4 * l], p[5 * l], p[6 * l], p[7 * l]};
+        u32x2 a[3], b[3];
+        split_pack4(lo4, a[0], a[1], a[2]);
+        split_pack4(hi4, b[0], b[1], b[2]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) w.p[q][c] = u32x4{a[q][0], a[q][1], b[q][0], b[q][1]};
+    }
+}
+
+template <bool DO_GA, bool DO_DW>
+__global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short Gp[DO_GA ? 3 * PLANE : 8];      // G tile, row-major planes
+    __shared__ __attribute__((aligned(16))) unsigned short GT[DO_DW ? 3 * TPLANE : 8];     // G tile, transposed planes
+    __shared__ __attribute__((aligned(16))) unsigned short AT[DO_DW ? 3 * TPLANE : 8];     // A tile, transposed planes
+    __shared__ __attribute__((aligned(16))) float Ot[tile_floats(H / 4)];                  // GA tile; bias sums at the end
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    WPlanes32 wt;
+    if constexpr (DO_GA) load_wplanes32_t(wt, a.W, a.ldw, a.koff + 32 * w + j, h);
+    f32x16 dw[DO_DW ? 4 : 1];
+#pragma unroll
+    for (int kb = 0; kb < (DO_DW ? 4 : 1); ++kb) dw[kb] = zero16();
+    f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
+    int t0, t1;
+    tile_range(a.rows, t0, t1);
+    const int srow = t >> 5, sq = t & 31;             // this thread stages rows 2*srow + 16*it + {0, 1}, columns 4*sq..
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pg[4], pa[4], pm[4], pr[4];
+    auto prefetch = [&](int tile) {
+        const long long base = (long long)tile * TM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long long n = min(base + 2 * srow + 16 * (i >> 1) + (i & 1), a.rows - 1);
+            const size_t o = (size_t)n * H + 4 * sq;
+            pg[i] = *(const f32x4*)(a.G + o);
+            if constexpr (DO_DW) pa[i] = *(const f32x4*)(a.A + o);
+            if constexpr (DO_GA) {
+                if (a.mask) pm[i] = *(const f32x4*)(a.mask + o);
+                if (a.res) pr[i] = *(const f32x4*)(a.res + o);
+            }
+        }
+    };
+    if (t0 < t1) prefetch(t0);
+    for (int tile = t0; tile < t1; ++tile) {
+        const long long base = (long long)tile * TM;
+        const int nvalid = (int)min((long long)TM, a.rows - base);
+        f32x4 cm[4], cr[4];
+        __syncthreads();                           // the previous tile's products and output pass are done
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int r0 = 2 * srow + 16 * it;
+            const f32x4 g0 = r0 < nvalid ? pg[2 * it] : zero4;          // rows past the end add nothing to the sums
+            const f32x4 g1 = r0 + 1 < nvalid ? pg[2 * it + 1] : zero4;
+            dbacc += g0 + g1;
+            stage_rows2<DO_GA, DO_DW>(Gp, GT, r0, 4 * sq, g0, g1);
+            if constexpr (DO_DW) stage_rows2<false, true>(nullptr, AT, r0, 4 * sq, pa[2 * it], pa[2 * it + 1]);
+        }
+        if constexpr (DO_GA) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { cm[i] = pm[i]; cr[i] = pr[i]; }
+        }
+        __syncthreads();
+        if (tile + 1 < t1) prefetch(tile + 1);
+        if constexpr (DO_GA) {
+            f32x16 acc = zero16();
+            acc = wave_gemm3_32<0, 8>(Gp, wt, j, h, acc);
+            acc_to_tile(Ot, acc, w, j, h);
+        }
+        if constexpr (DO_DW) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int blk = 2 * s + h;
+                const unsigned short* gp = GT + tpos(32 * w + j, blk);
+                const u32x4 gh = *(const u32x4*)gp, gm = *(const u32x4*)(gp + TPLANE), gl = *(const u32x4*)(gp + 2 * TPLANE);
+                u32x4 ah[4], am[4], al[4];
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const unsigned short* ap = AT + tpos(32 * kb + j, blk);
+                    ah[kb] = *(const u32x4*)ap; am[kb] = *(const u32x4*)(ap + TPLANE); al[kb] = *(const u32x4*)(ap + 2 * TPLANE);
+                }
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gl, ah[kb], dw[kb]);    // smallest terms first
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gh, al[kb], dw[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gm, am[kb], dw[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gm, ah[kb], dw[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gh, am[kb], dw[kb]);
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gh, ah[kb], dw[kb]);
+            }
+        }
+        if constexpr (DO_GA) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 2 * srow + 16 * (i >> 1) + (i & 1);
+                if (row < nvalid) {
+                    f32x4 val = *(const f32x4*)(Ot + toff(row, sq, H / 4));
+                    if (a.mask) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) val[k] = cm[i][k] > 0.f ? val[k] : 0.f;
+                    }
+                    if (a.res) val += cr[i];
+                    *(f32x4*)(a.GA + (size_t)(base + row) * H + 4 * sq) = val;
+                }
+            }
+        }
+    }
+    if constexpr (DO_DW) {
+        float* p = a.partial + (size_t)blockIdx.x * PARTIAL;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int f = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                p[f * H + 32 * kb + j] = dw[kb][reg];
+            }
+        __syncthreads();
+        *(f32x4*)(Ot + srow * H + 4 * sq) = dbacc;
+        __syncthreads();
+        if (t < H) {
+            float sum = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) sum += Ot[g * H + t];
+            p[PARTIAL_W + t] = sum;
+        }
+    }
+}
+
 // out[(i / width) * ld + (i % width)] = sum over blocks of partial[b * stride + offset + i].  Eight
 // independent running sums per thread (blocks b = k mod 8) keep eight loads in flight; they are
 // combined pairwise in a fixed order, so the result does not depend on the launch.
@@ -488,11 +668,17 @@ extern "C" int mgn_train_linear_bwd(const float* G, const float* A, const float*
     MGN_REQUIRE(!GA || (W && ldw >= H && koff >= 0 && koff + H <= ldw), "mgn_train_linear_bwd");
     MGN_REQUIRE(!dW || (A && scratch && lddw >= H), "mgn_train_linear_bwd");
     MGN_REQUIRE(!db || dW, "mgn_train_linear_bwd");
+    MGN_REQUIRE(ldw % 4 == 0 || !GA, "mgn_train_linear_bwd");
     LinBwdArgs a{G, A, W, ldw, koff, mask, res, GA, (float*)scratch, rows};
-    int g = train_grid(rows, 2);
+    const bool split = mgn_matmul_mode() >= 1;           // bf16 split products; "f32" keeps the fp32 matrix pipe
+    int g = train_grid(rows, split ? 1 : 2);
     if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX - TRAIN_BLOCKS_MAX % 8;
     hipStream_t s = (hipStream_t)stream;
-    if (GA && dW) hipLaunchKernelGGL((train_linear_bwd_kernel<true, true>), dim3(g), dim3(NT), 0, s, a);
+    if (split) {
+        if (GA && dW) hipLaunchKernelGGL((train_linear_bwd3_kernel<true, true>), dim3(g), dim3(NT), 0, s, a);
+        else if (GA) hipLaunchKernelGGL((train_linear_bwd3_kernel<true, false>), dim3(g), dim3(NT), 0, s, a);
+        else hipLaunchKernelGGL((train_linear_bwd3_kernel<false, true>), dim3(g), dim3(NT), 0, s, a);
+    } else if (GA && dW) hipLaunchKernelGGL((train_linear_bwd_kernel<true, true>), dim3(g), dim3(NT), 0, s, a);
     else if (GA) hipLaunchKernelGGL((train_linear_bwd_kernel<true, false>), dim3(g), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((train_linear_bwd_kernel<false, true>), dim3(g), dim3(NT), 0, s, a);
     if (dW) {
