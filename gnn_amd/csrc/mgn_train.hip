@@ -468,6 +468,306 @@ __global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) 
     }
 }
 
+// ------------------------------------------------------------------------ edge update backward, fused
+// Backward of  e' = LN(ReLU(W2 ReLU(ps[s] + pr[r] + W0e e) + b2))  from the block's INPUTS only: the two
+// hidden activations are recomputed per 32-edge tile with exactly the arithmetic of mp_edge_h4_kernel
+// (same split, same products, same order), so their ReLU patterns are the forward's.  Per tile:
+//   1  h1 = ReLU(ps[s] + pr[r] + W0e e)        fp16-split product; kept in registers (mask), written as
+//                                               fp16 planes (product 2) and transposed bf16 planes (dW2)
+//   2  v = ReLU(W2 h1 + b2), LayerNorm statistics;  gy = ge + gaggr[r];  LayerNorm backward -> g2
+//      (two row reductions through LDS); g2 as row-major and transposed bf16 planes
+//   3  dW2 += g2^T h1;  g1 = (g2 W2) * (h1 > 0)   split-bf16 products
+//   4  g1 -> global (coalesced), dpr[r] = sum of g1 over the in-edges of r (same scan as the forward)
+// db2, dgamma, dbeta accumulate per lane in accumulator layout and are reduced once at the end.
+// Workgroups own whole receivers (contiguous CSR ranges), one workgroup per CU.
+struct EdgeBwdArgs {
+    const float* el; const float* ge; const float* gaggr; const float* ps; const float* pr;
+    const int* sender; const int* recv; const int* rowptr;
+    const float* w0; const float* w1; const float* b1; const float* ln_w;
+    float* g1; float* dpr; float* partial; int n_nodes; int n_edges;
+};
+
+constexpr int PARTIAL_E = H * H + 3 * H;     // dW2 | db2 | dgamma | dbeta
+constexpr int PKH = H + 8;                   // halves per row of an fp16 plane
+constexpr int PLH = TM * PKH;                // halves per fp16 plane
+
+__device__ __forceinline__ float swap_lane1(float x) {       // value of lane ^ 1
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+
+// accumulator layout (row j = lane & 31; register 4g+k holds feature 32w + 8g + 4h + k) -> transposed bf16
+// planes.  Lanes j and j^1 hold neighbouring rows of the same features: they swap values so that each
+// writes whole dwords (two rows of one feature), eight features per lane.
+__device__ __forceinline__ void tstore_acc(unsigned short* tp, const f32x16& v, int w, int j, int h) {
+    const bool odd = j & 1;
+    const int r0 = j & ~1;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float o0 = swap_lane1(v[2 * p]), o1 = swap_lane1(v[2 * p + 1]);
+        const float mine = odd ? v[2 * p + 1] : v[2 * p], other = odd ? o1 : o0;
+        unsigned ha, ma, la, hb, mb, lb;
+        split3(odd ? other : mine, ha, ma, la);      // row r0
+        split3(odd ? mine : other, hb, mb, lb);      // row r0 + 1
+        const int g = p >> 1, k = 2 * (p & 1) + (odd ? 1 : 0);
+        const int f = 32 * w + 8 * g + 4 * h + k;
+        unsigned* d = (unsigned*)(tp + tpos(f, r0 >> 3) + (r0 & 7));
+        d[0] = pack_hi16(ha, hb);
+        d[TPLANE / 2] = pack_hi16(ma, mb);
+        d[TPLANE] = pack_hi16(la, lb);
+    }
+}
+
+__global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short elP[2 * PLH];        // e tile, fp16 planes
+    __shared__ __attribute__((aligned(16))) unsigned short h1P[2 * PLH];        // h1 tile, fp16 planes; then Ot
+    __shared__ __attribute__((aligned(16))) unsigned short H1T[3 * TPLANE];     // h1 tile, transposed bf16 planes
+    __shared__ __attribute__((aligned(16))) unsigned short G2P[3 * PLANE];      // g2 tile, row-major bf16 planes
+    __shared__ __attribute__((aligned(16))) unsigned short G2T[3 * TPLANE];     // g2 tile, transposed bf16 planes
+    __shared__ __attribute__((aligned(16))) float vec[2][H];                    // W_SCALE * b2, gamma
+    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
+    __shared__ __attribute__((aligned(16))) float red2[LN_RED_FLOATS];
+    __shared__ float cout[H], tcarry[H];
+    __shared__ int srange[2];
+    float* Ot = (float*)h1P;                         // g1 tile (fp32); h1P is dead once product 2 has run
+    static_assert(sizeof(h1P) >= sizeof(float) * tile_floats(H / 4), "Ot must fit into h1P");
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    WPlanesH<8> wa, wb;
+    WPlanes32 w2t;
+    load_wplanes_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
+    load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    load_wplanes32_t(w2t, a.w1, H, 32 * w + j, h);
+    if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; tcarry[t] = 0.f; }
+    if (t == 0) {
+        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+        const long long first = a.rowptr[0];
+        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
+        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
+        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
+    }
+    f32x16 dw2[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) dw2[kb] = zero16();
+    f32x16 db2 = zero16(), dgam = zero16(), dbet = zero16();
+    __syncthreads();
+    const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
+    const int last = e1 - e0 - 1;                    // row offsets are relative to e0 and clamped to [0, last]
+    if (e0 < e1) {
+    const float* el_g = a.el + (size_t)e0 * H;
+    const float* ge_g = a.ge ? a.ge + (size_t)e0 * H : nullptr;
+    float* g1_g = a.g1 + (size_t)e0 * H;
+    const int* snd_g = a.sender + e0;
+    const int* rcv_g = a.recv + e0;
+    const int srow = t >> 5, sq = t & 31;            // row map: rows srow + 8*it, 16-byte chunk sq
+    const int sc = t & (H - 1);                      // scan map: column sc, rows 16*sg .. 16*sg+15
+    const int sg = __builtin_amdgcn_readfirstlane(t >> 7);
+
+    f32x4 pre[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) pre[it] = *(const f32x4*)(el_g + (unsigned)(min(srow + 8 * it, last) * H + 4 * sq));
+    int s_cur = snd_g[min(j, last)], r_cur = rcv_g[min(j, last)];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) hplanes_store4(elP, PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);
+    __syncthreads();
+    for (int rel = 0; rel <= last; rel += TM) {
+        const int nvalid = min(TM, last + 1 - rel);
+        const bool valid = j < nvalid;
+        // requests
+        f32x4 gs[4], gr[4], ye[4], ya[4];
+        const unsigned so = (unsigned)s_cur * H + 32 * w + 4 * h, ro = (unsigned)r_cur * H + 32 * w + 4 * h;
+        const unsigned eo = (unsigned)min(rel + j, last) * H + 32 * w + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gs[g] = *(const f32x4*)(a.ps + so + 8 * g); gr[g] = *(const f32x4*)(a.pr + ro + 8 * g); }
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            pre[it] = *(const f32x4*)(el_g + (unsigned)(min(rel + TM + srow + 8 * it, last) * H + 4 * sq));
+        const int s_nxt = snd_g[min(rel + TM + j, last)], r_nxt = rcv_g[min(rel + TM + j, last)];
+        const int ra = r_cur;
+        const int rb = (rel + j + 1 <= last) ? rcv_g[rel + j + 1] : -1;
+
+        // ---- 1: first hidden activation (the forward's arithmetic)
+        f32x16 acc = zero16();
+        acc = wave_gemm_h<0, 8, 8>(elP, PLH, PKH, 0, wa, j, h, acc);
+        unsigned hmask = 0;                          // bit i: h1 of accumulator register i is positive
+        {
+            f32x16 h1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    v[k] = fmaxf(fmaf(acc[4 * g + k], W_UNSCALE, gs[g][k] + gr[g][k]), 0.f);
+                    h1[4 * g + k] = v[k];
+                    hmask |= v[k] > 0.f ? 1u << (4 * g + k) : 0u;
+                }
+                hplanes_store4(h1P, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
+            }
+            tstore_acc(H1T, h1, w, j, h);
+        }
+        // upstream gradient rows (accumulator layout), consumed after the second product
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ya[g] = *(const f32x4*)(a.gaggr + ro + 8 * g);
+            ye[g] = ge_g ? *(const f32x4*)(ge_g + eo + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __syncthreads();                                                     // (B) h1 planes complete; elP dead
+        // ---- 2: second hidden activation, LayerNorm statistics
+        acc = acc_from_vec(vec[0], w, h);
+        acc = wave_gemm_h<0, 8, 8>(h1P, PLH, PKH, 0, wb, j, h, acc);
+        acc = relu16(acc);                                                   // W_SCALE * v
+        ln_local_stats_rows(acc, red, w, j, h);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) hplanes_store4(elP, PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);   // next tile
+        __syncthreads();                                                     // (C) statistics exchanged; h1P dead
+        float rstd;
+        f32x16 xh, g2;
+        {
+            const f32x4 ma = *(const f32x4*)(red + j * LN_RED_LD), mb = *(const f32x4*)(red + j * LN_RED_LD + 4);
+            const f32x4 qa = *(const f32x4*)(red + j * LN_RED_LD + 8), qb = *(const f32x4*)(red + j * LN_RED_LD + 12);
+            const float mean = (((ma[0] + ma[1]) + (ma[2] + ma[3])) + ((mb[0] + mb[1]) + (mb[2] + mb[3]))) * 0.125f;
+            const float m2 = ((qa[0] + qa[1]) + (qa[2] + qa[3])) + ((qb[0] + qb[1]) + (qb[2] + qb[3]));
+            const f32x4 da = ma - mean, db = mb - mean;
+            const float between = ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) +
+                                  ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
+            const float var = (m2 + 16.0f * between) * (1.0f / H);
+            rstd = __builtin_amdgcn_rsqf(var + LN_EPS * W_SCALE * W_SCALE);          // of the scaled values
+            const float shift = -mean * rstd;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xh[i] = fmaf(acc[i], rstd, shift);
+        }
+        // upstream gradient of e' (edge latent residual branch + receiver aggregate), LayerNorm backward
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 ga = *(const f32x4*)(vec[1] + 32 * w + 8 * g + 4 * h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 4 * g + k;
+                const float gy = valid ? ye[g][k] + ya[g][k] : 0.f;          // rows past the end add nothing
+                dbet[i] += gy;
+                dgam[i] = fmaf(gy, xh[i], dgam[i]);
+                const float ghv = gy * ga[k];
+                g2[i] = ghv;
+                s1 += ghv;
+                s2 = fmaf(ghv, xh[i], s2);
+            }
+        }
+        red2[j * LN_RED_LD + 2 * w + h] = s1;
+        red2[j * LN_RED_LD + 8 + 2 * w + h] = s2;
+        __syncthreads();                                                     // (C2) row sums exchanged
+        {
+            const f32x4 pa = *(const f32x4*)(red2 + j * LN_RED_LD), pb = *(const f32x4*)(red2 + j * LN_RED_LD + 4);
+            const f32x4 qa = *(const f32x4*)(red2 + j * LN_RED_LD + 8), qb = *(const f32x4*)(red2 + j * LN_RED_LD + 12);
+            const float m1 = (((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) * (1.0f / H);
+            const float m2 = (((qa[0] + qa[1]) + (qa[2] + qa[3])) + ((qb[0] + qb[1]) + (qb[2] + qb[3]))) * (1.0f / H);
+            const float rs = rstd * W_SCALE;                                 // 1 / sqrt(var(v) + eps)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float gv = rs * (g2[i] - m1 - xh[i] * m2);
+                g2[i] = acc[i] > 0.f ? gv : 0.f;                             // through the ReLU that produced v
+                db2[i] += g2[i];
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            planes_store4(G2P, j, 32 * w + 8 * g + 4 * h, f32x4{g2[4 * g], g2[4 * g + 1], g2[4 * g + 2], g2[4 * g + 3]});
+        tstore_acc(G2T, g2, w, j, h);
+        __syncthreads();                                                     // (D) g2 planes complete
+        // ---- 3: dW2 += g2^T h1,  g1 = (g2 W2) * (h1 > 0)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int blk = 2 * s + h;
+            const unsigned short* gp = G2T + tpos(32 * w + j, blk);
+            const u32x4 gh = *(const u32x4*)gp, gm = *(const u32x4*)(gp + TPLANE), gl = *(const u32x4*)(gp + 2 * TPLANE);
+            u32x4 ah[4], am[4], al[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const unsigned short* ap = H1T + tpos(32 * kb + j, blk);
+                ah[kb] = *(const u32x4*)ap; am[kb] = *(const u32x4*)(ap + TPLANE); al[kb] = *(const u32x4*)(ap + 2 * TPLANE);
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gl, ah[kb], dw2[kb]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gh, al[kb], dw2[kb]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gm, am[kb], dw2[kb]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gm, ah[kb], dw2[kb]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gh, am[kb], dw2[kb]);
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gh, ah[kb], dw2[kb]);
+        }
+        acc = zero16();
+        acc = wave_gemm3_32<0, 8>(G2P, w2t, j, h, acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = (hmask >> i) & 1u ? acc[i] : 0.f;
+        acc_to_tile(Ot, acc, w, j, h);
+        __syncthreads();                                                     // (E) g1 tile complete
+        // ---- 4: g1 rows to memory, receiver-segmented sums
+        const unsigned mask = (unsigned)__ballot(valid && ra != rb);         // bit r: row r ends its segment
+        const unsigned gmask = (mask >> (16 * sg)) & 0xFFFFu;
+        float xr[16], part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xr[r] = Ot[(16 * sg + r) * (H + 4) + sc];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            part += xr[r];
+            xr[r] = part;
+            if ((gmask >> r) & 1u) part = 0.f;
+        }
+        float cin = tcarry[sc];
+        if (sg == 0) cout[sc] = gmask ? part : cin + part;
+        f32x4 y[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) y[it] = *(const f32x4*)(Ot + toff(srow + 8 * it, sq, H / 4));
+        __syncthreads();                                                     // (S) cout visible
+        if (sg == 1) cin = cout[sc];
+        {
+            float* go = g1_g + (unsigned)(rel * H);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
+                if (row < nvalid) *(f32x4*)(go + (unsigned)(row * H + 4 * sq)) = y[it];
+            }
+        }
+        bool open = true;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((gmask >> r) & 1u) {
+                const int node = __builtin_amdgcn_readlane(ra, 16 * sg + r);
+                a.dpr[(unsigned)(node * H + sc)] = open ? cin + xr[r] : xr[r];
+                open = false;
+            }
+        }
+        if (sg == 1) tcarry[sc] = gmask ? part : cin + part;
+        __syncthreads();                                                     // (F) Ot / tcarry settled
+        s_cur = s_nxt; r_cur = r_nxt;
+    }
+    }
+    // ---- partial sums of this workgroup
+    float* p = a.partial + (size_t)blockIdx.x * PARTIAL_E;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int f = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            p[f * H + 32 * kb + j] = dw2[kb][reg];
+        }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {                    // column sums of the per-lane (per-row) accumulators
+        __syncthreads();
+        acc_to_tile(Ot, q == 0 ? db2 : (q == 1 ? dgam : dbet), w, j, h);
+        __syncthreads();
+        if (t < H) {
+            float sum = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < TM; ++r) sum += Ot[r * (H + 4) + t];
+            p[H * H + q * H + t] = sum;
+        }
+    }
+}
+
 // out[(i / width) * ld + (i % width)] = sum over blocks of partial[b * stride + offset + i].  Eight
 // independent running sums per thread (blocks b = k mod 8) keep eight loads in flight; they are
 // combined pairwise in a fixed order, so the result does not depend on the launch.
@@ -689,6 +989,30 @@ extern "C" int mgn_train_linear_bwd(const float* G, const float* A, const float*
                                PARTIAL_W, H, H, H, db);
     }
     return check_launch("mgn_train_linear_bwd");
+}
+
+extern "C" int mgn_train_edge_bwd(const float* e_in, const float* g_e, const float* g_aggr, const float* ps,
+                                  const float* pr, const int32_t* sender, const int32_t* recv, const int32_t* rowptr,
+                                  const float* w0, const float* w1, const float* b1, const float* ln_w, float* g1,
+                                  float* dpr, float* dW1, float* db1, float* dgamma, float* dbeta, void* scratch,
+                                  int64_t n_nodes, int64_t n_edges, void* stream) {
+    MGN_REQUIRE(n_nodes > 0 && n_edges > 0 && n_nodes < (1ll << 24) && n_edges < (1ll << 24), "mgn_train_edge_bwd");
+    MGN_REQUIRE(e_in && g_aggr && ps && pr && sender && recv && rowptr && w0 && w1 && b1 && ln_w, "mgn_train_edge_bwd");
+    MGN_REQUIRE(g1 && dpr && dW1 && db1 && dgamma && dbeta && scratch, "mgn_train_edge_bwd");
+    hipStream_t s = (hipStream_t)stream;
+    // receivers without in-edges are never visited by the scan
+    if (hipMemsetAsync(dpr, 0, (size_t)n_nodes * H * sizeof(float), s) != hipSuccess) return check_launch("mgn_train_edge_bwd");
+    EdgeBwdArgs a{e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, ln_w, g1, dpr, (float*)scratch,
+                  (int)n_nodes, (int)n_edges};
+    const int g = train_grid(n_edges, 1);
+    hipLaunchKernelGGL(train_edge_bwd_kernel, dim3(g), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(PARTIAL_W / 64), dim3(64), 0, s, (const float*)scratch, g, PARTIAL_E, 0,
+                       PARTIAL_W, H, H, dW1);
+    float* outs[3] = {db1, dgamma, dbeta};
+    for (int q = 0; q < 3; ++q)
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, s, (const float*)scratch, g, PARTIAL_E,
+                           PARTIAL_W + q * H, H, H, H, outs[q]);
+    return check_launch("mgn_train_edge_bwd");
 }
 
 extern "C" int mgn_segment_sum(const float* src, const int32_t* rowptr, const int32_t* order, float* out,

@@ -284,6 +284,14 @@ def scatter_rows(src, idx, dst):
 
 
 # --------------------------------------------------------------------------- device: training blocks
+def matmul_mode() -> str:
+    """The matrix path libmgn_hip.so selects from the environment (MGN_MATMUL): "f16x2" (default),
+    "bf16x3" or "f32"."""
+    import os
+    v = os.environ.get("MGN_MATMUL", "")
+    return v if v in ("f32", "bf16x3") else "f16x2"
+
+
 def train_scratch_bytes() -> int:
     return int(_lib.lib().mgn_train_scratch_bytes())
 
@@ -369,6 +377,22 @@ def train_linear_bwd(g, scratch, a=None, w=None, koff=0, mask=None, res=None, ga
         _opt(ga, torch.float32, (rows, H), "GA"), dw_ptr, lddw, _opt(db, torch.float32, (H,), "db"),
         _scratch(scratch), rows, _stream())
     _lib.check(rc, "mgn_train_linear_bwd")
+
+
+def train_edge_bwd(e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, ln_w, g1, dpr, dw1, db1, dgamma, dbeta,
+                   scratch):
+    """Fused backward of one block's edge MLP with recomputed hidden activations (default matrix path)."""
+    e, n = e_in.shape[0], dpr.shape[0]
+    rc = _lib.lib().mgn_train_edge_bwd(
+        _rows128(e_in, "e_in"), _opt(g_e, torch.float32, (e, H), "g_e"), _dev(g_aggr, torch.float32, (None, H), "g_aggr"),
+        _dev(ps, torch.float32, (None, H), "ps"), _dev(pr, torch.float32, (None, H), "pr"),
+        _dev(sender, torch.int32, (e,), "sender"), _dev(recv, torch.int32, (e,), "recv"),
+        _dev(rowptr, torch.int32, (n + 1,), "rowptr"), _dev(w0, torch.float32, (H, 3 * H), "w0"),
+        _dev(w1, torch.float32, (H, H), "w1"), _dev(b1, torch.float32, (H,), "b1"), _dev(ln_w, torch.float32, (H,), "ln_w"),
+        _rows128(g1, "g1", e), _rows128(dpr, "dpr"), _dev(dw1, torch.float32, (H, H), "dW1"),
+        _dev(db1, torch.float32, (H,), "db1"), _dev(dgamma, torch.float32, (H,), "dgamma"),
+        _dev(dbeta, torch.float32, (H,), "dbeta"), _scratch(scratch), n, e, _stream())
+    _lib.check(rc, "mgn_train_edge_bwd")
 
 
 def segment_sum(src, rowptr, out, order=None):

@@ -9,6 +9,7 @@ components out and the parameter gradients back; no arithmetic of the model runs
 """
 from __future__ import annotations
 
+import os
 import threading
 from typing import Dict, List
 
@@ -53,9 +54,18 @@ def _pad_rows(w: torch.Tensor, b: torch.Tensor):
     return wp, bp
 
 
-def forward_saving(model, graph, target_norm: torch.Tensor):
+def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hidden: bool = False):
     """Runs the forward pass with the training kernels.  Returns (loss3 [3], saved) where
-    ``saved`` holds what ``backward`` needs."""
+    ``saved`` holds what ``backward`` needs.
+
+    ``fused`` (default: on for the default matrix path): the edge update of every block runs in the
+    inference kernel and keeps only its input; the backward recomputes the two hidden activations
+    tile by tile (``mgn_train_edge_bwd``).  Otherwise every Linear / LayerNorm is its own launch
+    and both hidden activations of every edge MLP are kept.  ``keep_hidden`` (diagnostics): the fused
+    path also evaluates and keeps the two hidden activations, from the same inputs and with the same
+    arithmetic as the fused kernels, so that a caller can read the ReLU pattern of the step."""
+    if fused is None:
+        fused = ops.matmul_mode() == "f16x2" and os.environ.get("MGN_TRAIN_FUSED", "1") != "0"
     halo = model.__dict__.get("halo")
     dev = graph["mesh_pos"].device
     if dev.type != "cuda":
@@ -105,32 +115,45 @@ def forward_saving(model, graph, target_norm: torch.Tensor):
     el, enc_e = encoder(model.edge_encoder, ef_pad)
 
     layers: List[tuple] = []
-    ps, pr, eprime = _empty(n_loc, dev), _empty(n, dev), _empty(e, dev)
+    ps, pr, eprime = _empty(n_loc, dev), _empty(n_loc if fused else n, dev), (None if fused else _empty(e, dev))
     rowptr = topo.rowptr[: n + 1]                   # halo nodes receive nothing here: their rows stay with the owners
     blocks = list(model.processors)
     for i, blk in enumerate(blocks):
         em, nm = blk.edge_mlp, blk.node_mlp
         w0 = em[0].weight.detach()
+        if fused and i > 0:
+            ps, pr = _empty(n_loc, dev), _empty(n_loc, dev)      # every block's projections are kept for the backward
         ops.train_linear_fwd(x, w0, 0, ps[:n])
         if halo is not None:
             pending = halo.exchange_rows(ps, async_op=True)      # sender projections of the halo nodes
-        ops.train_linear_fwd(x, w0, H, pr, bias=em[0].bias.detach())
+        ops.train_linear_fwd(x, w0, H, pr[:n], bias=em[0].bias.detach())
         if halo is not None and pending is not None:
             pending.wait()
-        h1e, ve = _empty(e, dev), _empty(e, dev)
-        ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
-        ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
         last = i + 1 == len(blocks)
-        e_next = None if last else _empty(e, dev)          # the edge latents after the last block are unused
-        ops.train_ln_fwd(ve, em[4].weight.detach(), em[4].bias.detach(), y=eprime,
-                         res=None if last else el, yres=e_next)
-        aggr = _empty(n, dev)
-        ops.segment_sum(eprime, rowptr, aggr)
+        if fused:
+            # whole edge update in one kernel; hidden activations are recomputed in the backward
+            aggr = torch.zeros(n, H, dtype=torch.float32, device=dev)     # receivers without in-edges stay 0
+            e_next = _empty(e, dev)
+            ops.mp_edge(el, ps, pr, topo.rowptr, topo.sender, topo.recv, em.weights(), e_next, aggr)
+            h1e = ve = None
+            if keep_hidden:
+                h1e, ve = _empty(e, dev), _empty(e, dev)
+                ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
+                ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
+        else:
+            h1e, ve = _empty(e, dev), _empty(e, dev)
+            ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
+            ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
+            e_next = None if last else _empty(e, dev)      # the edge latents after the last block are unused
+            ops.train_ln_fwd(ve, em[4].weight.detach(), em[4].bias.detach(), y=eprime,
+                             res=None if last else el, yres=e_next)
+            aggr = _empty(n, dev)
+            ops.segment_sum(eprime, rowptr, aggr)
         h1n, vn, x_next = _empty(n, dev), _empty(n, dev), _empty(n, dev)
         ops.train_linear_fwd(x, nm[0].weight.detach(), 0, h1n, b=aggr, koff_b=H, bias=nm[0].bias.detach(), relu=True)
         ops.train_linear_fwd(h1n, nm[2].weight.detach(), 0, vn, bias=nm[2].bias.detach(), relu=True)
         ops.train_ln_fwd(vn, nm[4].weight.detach(), nm[4].bias.detach(), res=x, yres=x_next)
-        layers.append((x, el, h1e, ve, aggr, h1n, vn))
+        layers.append((x, el, h1e, ve, aggr, h1n, vn, ps if fused else None, pr if fused else None))
         x, el = x_next, e_next
 
     dec = model.node_decoder
@@ -142,7 +165,7 @@ def forward_saving(model, graph, target_norm: torch.Tensor):
     ops.train_loss_fwd(decoded, target_norm, node_type, T, loss3, scratch)
     if halo is not None:
         halo.all_reduce_(loss3)                     # every term of the loss is a sum over nodes
-    saved = dict(topo=topo, halo=halo, enc_n=enc_n, enc_e=enc_e, layers=layers, x_last=x, hd=hd, decoded=decoded, w2p=w2p,
+    saved = dict(topo=topo, halo=halo, fused=fused, enc_n=enc_n, enc_e=enc_e, layers=layers, x_last=x, hd=hd, decoded=decoded, w2p=w2p,
                  target_norm=target_norm, node_type=node_type)
     return loss3, saved
 
@@ -182,14 +205,14 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
     g2n, g1n, gaggr, dpr = (_empty(n, dev) for _ in range(4))
     dps_loc = _empty(n_loc, dev)
     dps = dps_loc[:n]
-    g2e, g1e = _empty(e, dev), _empty(e, dev)
+    g2e, g1e = (None if saved["fused"] else _empty(e, dev)), _empty(e, dev)
     s_rowptr, s_order = topo.sender_view()
     rowptr = topo.rowptr[: n + 1]
     blocks = list(model.processors)
     for i in range(len(blocks) - 1, -1, -1):
         blk, pre = blocks[i], f"processors.{i}."
         em, nm = blk.edge_mlp, blk.node_mlp
-        x, el, h1e, ve, aggr, h1n, vn = saved["layers"][i]
+        x, el, h1e, ve, aggr, h1n, vn, ps_b, pr_b = saved["layers"][i]
         # node MLP: x_next = x + LN(ReLU(V2 ReLU(V1 [x, aggr] + c1) + c2))
         dg, dbt = vec(), vec()
         ops.train_ln_bwd(vn, nm[4].weight.detach(), g2n, dg, dbt, scratch, g=gx, relu_mask=True)
@@ -204,10 +227,15 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
         grads[pre + "node_mlp.0.weight"], grads[pre + "node_mlp.0.bias"] = dw, db
         # edge MLP: e' = LN(ReLU(W2 ReLU(ps[s] + pr[r] + W0e e) + b2)); upstream = ge + gaggr[receiver]
         dg, dbt = vec(), vec()
-        ops.train_ln_bwd(ve, em[4].weight.detach(), g2e, dg, dbt, scratch, g=ge, gg=gaggr, idx=topo.recv, relu_mask=True)
-        grads[pre + "edge_mlp.4.weight"], grads[pre + "edge_mlp.4.bias"] = dg, dbt
         dw, db = g_like(em[2].weight), vec()
-        ops.train_linear_bwd(g2e, scratch, a=h1e, w=em[2].weight.detach(), mask=h1e, ga=g1e, dw=dw, db=db)
+        if saved["fused"]:
+            ops.train_edge_bwd(el, ge, gaggr, ps_b, pr_b, topo.sender, topo.recv, rowptr, em[0].weight.detach(),
+                               em[2].weight.detach(), em[2].bias.detach(), em[4].weight.detach(), g1e, dpr, dw, db, dg, dbt,
+                               scratch)
+        else:
+            ops.train_ln_bwd(ve, em[4].weight.detach(), g2e, dg, dbt, scratch, g=ge, gg=gaggr, idx=topo.recv, relu_mask=True)
+            ops.train_linear_bwd(g2e, scratch, a=h1e, w=em[2].weight.detach(), mask=h1e, ga=g1e, dw=dw, db=db)
+        grads[pre + "edge_mlp.4.weight"], grads[pre + "edge_mlp.4.bias"] = dg, dbt
         grads[pre + "edge_mlp.2.weight"], grads[pre + "edge_mlp.2.bias"] = dw, db
         dw0, db0 = g_like(em[0].weight), vec()
         w_e0 = em[0].weight.detach()
@@ -220,7 +248,8 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
         ops.segment_sum(g1e, s_rowptr, dps_loc, order=s_order)
         if halo is not None:
             pending = halo.return_rows(dps_loc, async_op=True)   # halo senders' sums go back to their owners
-        ops.segment_sum(g1e, rowptr, dpr)
+        if not saved["fused"]:
+            ops.segment_sum(g1e, rowptr, dpr)
         if halo is not None and pending is not None:
             pending.wait()
         ops.train_linear_bwd(dps, scratch, a=x, w=w_e0, koff=0, res=gx, ga=gx, dw=dw0, dw_koff=0)
@@ -244,6 +273,8 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
     encoder_bwd(model.node_encoder, "node_encoder", saved["enc_n"], gx, g2n, g1n)
     if ge is None:                                # no processor blocks: the edge encoder does not reach the loss
         ge = torch.zeros(e, H, dtype=torch.float32, device=dev)
+    if g2e is None:
+        g2e = _empty(e, dev)
     encoder_bwd(model.edge_encoder, "edge_encoder", saved["enc_e"], ge, g2e, g1e)
     if halo is not None:
         # each rank holds the sums over its own rows: one all-reduce over all 136 tensors (4.84 MB)

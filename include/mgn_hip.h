@@ -198,6 +198,20 @@ int mgn_train_ln_bwd(const float* G, const float* Gg, const int32_t* idx, const 
                      int32_t relu_mask, float* gpre, float* dgamma, float* dbeta, void* scratch, int64_t rows,
                      void* stream);
 
+/* Backward of the edge MLP of one processor block (core/meshgraphnet.py:95-96 with the MLP of :64-70)
+ * from the block's inputs: the hidden activations are recomputed tile by tile with the arithmetic of
+ * mgn_mp_edge's default matrix path, so nothing but e_in has to be kept from the forward pass.
+ *   upstream gradient of edge j:  g_e[j] (may be NULL) + g_aggr[recv[j]]       (residual :120 and sum :113)
+ *   g1[j]  = gradient wrt the output of the first Linear (after its ReLU mask), [E][128]
+ *   dpr[n] = sum of g1 over the in-edges of n (gradient of the receiver projection), [N][128]
+ *   dW1 [128][128], db1, dgamma, dbeta [128]: gradients of the second Linear and the LayerNorm.
+ * Edges in receiver-major order as for mgn_mp_edge; the gradients of the first Linear's three column
+ * blocks follow from g1 with mgn_train_linear_bwd / mgn_segment_sum. */
+int mgn_train_edge_bwd(const float* e_in, const float* g_e, const float* g_aggr, const float* ps, const float* pr,
+                       const int32_t* sender, const int32_t* recv, const int32_t* rowptr, const float* w0 /*[128][384]*/,
+                       const float* w1, const float* b1, const float* ln_w, float* g1, float* dpr, float* dW1, float* db1,
+                       float* dgamma, float* dbeta, void* scratch, int64_t n_nodes, int64_t n_edges, void* stream);
+
 /* nn.Linear backward for one 128-column block of the weight.  G = gradient wrt the layer's
  * output rows, A = the block's input rows.
  *   dW[f*lddw + k] = sum_r G[r,f] A[r,k]     (dW points at the block's first column; NULL to skip)

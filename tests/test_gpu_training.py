@@ -115,7 +115,7 @@ def gpu_loss_and_grads(model, g):
     gg = graph_to(g, DEV)
     cur = torch.cat([gg["world_pos"], gg["phi"]], -1)
     tgt = model.output_normalizer(gg["target"] - cur).contiguous()
-    loss3, saved = training.forward_saving(model, gg, tgt)
+    loss3, saved = training.forward_saving(model, gg, tgt, keep_hidden=True)      # the default path + its ReLU pattern
     grads = training.backward(model, saved, torch.ones(3, device=DEV))
     topo = saved["topo"]
     perm = topo.perm.cpu()
@@ -126,7 +126,7 @@ def gpu_loss_and_grads(model, g):
         return out
 
     masks = [saved["enc_n"][1].cpu() > 0, orig(saved["enc_e"][1].cpu() > 0)]
-    for (_x, _e, h1e, ve, _a, h1n, vn) in saved["layers"]:
+    for (_x, _e, h1e, ve, _a, h1n, vn, _ps, _pr) in saved["layers"]:
         masks += [orig(h1e.cpu() > 0), orig(ve.cpu() > 0), h1n.cpu() > 0, vn.cpu() > 0]
     masks.append(saved["hd"].cpu() > 0)
     return loss3.cpu(), {k: v.cpu() for k, v in grads.items()}, masks
@@ -258,3 +258,28 @@ def test_fused_adam_matches_torch_adam():
     sd = o_mine.state_dict()
     assert set(sd["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "params"}
     assert all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd["state"].values())
+
+
+def test_fused_edge_backward_matches_unfused():
+    """The training step that recomputes the edge MLP's hidden activations in the backward
+    (mgn_train_edge_bwd) against the step that keeps them: same loss, gradients equal to 2e-6
+    (the weight-gradient sums are grouped differently), on a mesh with ragged in-degrees."""
+    import copy
+    from gnn_amd import training
+    cfg = O.OracleConfig(process_steps=3)
+    sd = O.init_state_dict(cfg, 9)
+    g = O.synthetic_graph(37, 23, seed=4)
+    n = g["mesh_pos"].shape[0]
+    g["target"] = torch.cat([g["world_pos"], g["phi"]], -1).unsqueeze(0) + 1e-2 * torch.randn(1, n, 3, generator=torch.Generator().manual_seed(3))
+    gg = graph_to(g, DEV)
+    out = []
+    for fused in (True, False):
+        model = build_model(cfg, sd)
+        tgt = model._normalized_target(gg)
+        loss3, saved = training.forward_saving(model, gg, tgt, fused=fused)
+        assert saved["fused"] == fused
+        out.append((loss3.cpu(), {k: v.cpu() for k, v in training.backward(model, saved, torch.ones(3, device=DEV)).items()}))
+    (la, ga), (lb, gb) = out
+    assert rel_l2(la, lb) < 1e-6
+    worst = max((rel_l2(ga[k], gb[k]), k) for k in gb)
+    assert worst[0] < 2e-6, worst
