@@ -348,6 +348,29 @@ __device__ __forceinline__ f32x16 wave_gemm3_32(const unsigned short* tile, cons
     return acc;
 }
 
+// Diagnostic build only (-DMGN_PHASE_STAMPS, see scripts/phase_stamps.py; one table per translation unit): cycle sums between
+// stamps of a kernel's main loop, taken by lane 0 of waves 0 and 2.  Never in the product build.
+#ifdef MGN_PHASE_STAMPS
+__device__ unsigned long long g_stamps[2][16];
+#define STAMP_DECL unsigned long long st_prev = 0, st_sum[16] = {0}; bool st_on = false;
+#define STAMP(i)                                                                          \
+    do {                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        unsigned long long now_;                                                          \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");       \
+        if (st_on) st_sum[i] += now_ - st_prev;                                           \
+        st_prev = now_; st_on = true;                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+    } while (0)
+#define STAMP_FLUSH(slot)                                                                 \
+    if ((threadIdx.x & 63) == 0 && (slot) >= 0)                                           \
+        for (int i_ = 0; i_ < 16; ++i_) atomicAdd(&g_stamps[slot][i_], st_sum[i_]);
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(slot)
+#endif
+
 // Blocks b and b + 8 share an XCD (and its L2); hand each XCD a contiguous run of ranges.
 __device__ __forceinline__ int range_of_block(int b, int nb) {
     return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3);

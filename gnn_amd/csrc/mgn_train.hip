@@ -569,7 +569,9 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) hplanes_store4(elP, PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);
     __syncthreads();
+    STAMP_DECL
     for (int rel = 0; rel <= last; rel += TM) {
+        STAMP(0);
         const int nvalid = min(TM, last + 1 - rel);
         const bool valid = j < nvalid;
         // requests
@@ -586,8 +588,10 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         const int rb = (rel + j + 1 <= last) ? rcv_g[rel + j + 1] : -1;
 
         // ---- 1: first hidden activation (the forward's arithmetic)
+        STAMP(1);
         f32x16 acc = zero16();
         acc = wave_gemm_h<0, 8, 8>(elP, PLH, PKH, 0, wa, j, h, acc);
+        STAMP(2);
         unsigned hmask = 0;                          // bit i: h1 of accumulator register i is positive
         {
             f32x16 h1;
@@ -610,7 +614,9 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
             ya[g] = *(const f32x4*)(a.gaggr + ro + 8 * g);
             ye[g] = ge_g ? *(const f32x4*)(ge_g + eo + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        STAMP(3);
         __syncthreads();                                                     // (B) h1 planes complete; elP dead
+        STAMP(4);
         // ---- 2: second hidden activation, LayerNorm statistics
         acc = acc_from_vec(vec[0], w, h);
         acc = wave_gemm_h<0, 8, 8>(h1P, PLH, PKH, 0, wb, j, h, acc);
@@ -618,7 +624,9 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         ln_local_stats_rows(acc, red, w, j, h);
 #pragma unroll
         for (int it = 0; it < 4; ++it) hplanes_store4(elP, PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);   // next tile
+        STAMP(5);
         __syncthreads();                                                     // (C) statistics exchanged; h1P dead
+        STAMP(6);
         float rstd;
         f32x16 xh, g2;
         {
@@ -654,7 +662,9 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         }
         red2[j * LN_RED_LD + 2 * w + h] = s1;
         red2[j * LN_RED_LD + 8 + 2 * w + h] = s2;
+        STAMP(7);
         __syncthreads();                                                     // (C2) row sums exchanged
+        STAMP(8);
         {
             const f32x4 pa = *(const f32x4*)(red2 + j * LN_RED_LD), pb = *(const f32x4*)(red2 + j * LN_RED_LD + 4);
             const f32x4 qa = *(const f32x4*)(red2 + j * LN_RED_LD + 8), qb = *(const f32x4*)(red2 + j * LN_RED_LD + 12);
@@ -672,7 +682,9 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         for (int g = 0; g < 4; ++g)
             planes_store4(G2P, j, 32 * w + 8 * g + 4 * h, f32x4{g2[4 * g], g2[4 * g + 1], g2[4 * g + 2], g2[4 * g + 3]});
         tstore_acc(G2T, g2, w, j, h);
+        STAMP(9);
         __syncthreads();                                                     // (D) g2 planes complete
+        STAMP(10);
         // ---- 3: dW2 += g2^T h1,  g1 = (g2 W2) * (h1 > 0)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -698,12 +710,15 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
             for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gh, ah[kb], dw2[kb]);
         }
+        STAMP(11);
         acc = zero16();
         acc = wave_gemm3_32<0, 8>(G2P, w2t, j, h, acc);
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = (hmask >> i) & 1u ? acc[i] : 0.f;
         acc_to_tile(Ot, acc, w, j, h);
+        STAMP(12);
         __syncthreads();                                                     // (E) g1 tile complete
+        STAMP(13);
         // ---- 4: g1 rows to memory, receiver-segmented sums
         const unsigned mask = (unsigned)__ballot(valid && ra != rb);         // bit r: row r ends its segment
         const unsigned gmask = (mask >> (16 * sg)) & 0xFFFFu;
@@ -721,6 +736,7 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         f32x4 y[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) y[it] = *(const f32x4*)(Ot + toff(srow + 8 * it, sq, H / 4));
+        STAMP(14);
         __syncthreads();                                                     // (S) cout visible
         if (sg == 1) cin = cout[sc];
         {
@@ -741,9 +757,11 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
             }
         }
         if (sg == 1) tcarry[sc] = gmask ? part : cin + part;
+        STAMP(15);
         __syncthreads();                                                     // (F) Ot / tcarry settled
         s_cur = s_nxt; r_cur = r_nxt;
     }
+    STAMP_FLUSH(w == 0 ? 0 : (w == 2 ? 1 : -1))
     }
     // ---- partial sums of this workgroup
     float* p = a.partial + (size_t)blockIdx.x * PARTIAL_E;
@@ -905,6 +923,17 @@ int stream_grid(long long items, int per_block) {
 }
 
 }  // namespace
+
+#ifdef MGN_PHASE_STAMPS
+extern "C" int mgn_debug_read_train_stamps(unsigned long long* out32, int reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int64_t mgn_train_scratch_bytes(void) {
     return (int64_t)TRAIN_BLOCKS_MAX * PARTIAL * (int64_t)sizeof(float);

@@ -55,11 +55,13 @@ class HaloPlan:
         send_ids, self.send_counts = [], []
         src_owner = owner_of(snd)
         dst_owner = owner_of(rcv)
+        cross = np.nonzero((src_owner == rank) & (dst_owner != rank))[0]       # edges leaving this rank: few
+        cross_snd, cross_dst = snd[cross], dst_owner[cross]
         for q in range(world_size):
             if q == rank:
                 self.send_counts.append(0)
                 continue
-            need = np.unique(snd[(dst_owner == q) & (src_owner == rank)])
+            need = np.unique(cross_snd[cross_dst == q])
             send_ids.append(need - lo)
             self.send_counts.append(int(need.shape[0]))
         self.send_local_ids = np.concatenate(send_ids) if send_ids else np.zeros(0, dtype=np.int64)
