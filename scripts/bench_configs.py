@@ -63,3 +63,27 @@ for copies in (1, 8):
         m.predict(g)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
     print(f"100k mesh x{copies}: predict {dt * 1e3:.2f} ms, {copies / dt:.1f} trajectory-steps/s, {e * 15 / dt / 1e6:.0f} M edge-updates/s")
+
+# --- bending-size training step (loss + backward + Adam), the size of the reference's own training log
+from gnn_amd.optim import FusedAdam  # noqa: E402
+fr = gnn_amd.synthetic_frames(32, 16, n_frames=1, seed=0, lx=0.08, ly=0.01)[0]
+nb = fr["mesh_pos"].shape[0]
+fr["target"] = torch.cat([fr["world_pos"], fr["phi"]], -1).unsqueeze(0) + 1e-4 * torch.randn(1, nb, 3)
+fr = fr.to(dev)
+m = model_for(10).train()
+opt = FusedAdam(m.parameters(), lr=1e-4)
+
+
+def train_step():
+    opt.zero_grad()
+    m.loss(fr)[0].backward()
+    opt.step()
+
+
+for _ in range(5):
+    train_step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50):
+    train_step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 50
+print(f"bending 33x17 training step (loss + backward + Adam): {1 / dt:.1f} steps/s ({dt * 1e3:.2f} ms)")

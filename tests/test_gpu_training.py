@@ -283,3 +283,50 @@ def test_fused_edge_backward_matches_unfused():
     assert rel_l2(la, lb) < 1e-6
     worst = max((rel_l2(ga[k], gb[k]), k) for k in gb)
     assert worst[0] < 2e-6, worst
+
+
+def test_full_size_training_step_properties():
+    """The training configuration at its full size (500 x 500 nodes, 10 message-passing steps), where
+    the oracle's autograd is out of reach, through properties that do not depend on size:
+    the loss of the training path equals the loss formed from the inference path's ``forward``
+    (different kernels for every stage of the processor), and the gradient's directional
+    derivative matches a central finite difference of the loss along a random direction."""
+    import gnn_amd
+    from gnn_amd.meshgraphnet import EncodeProcessDecodeMultiScale
+    g = gnn_amd.synthetic_frames(499, 499, n_frames=1, seed=0)[0]
+    n = g["mesh_pos"].shape[0]
+    gen = torch.Generator().manual_seed(1)
+    g["target"] = torch.cat([g["world_pos"], g["phi"]], -1).unsqueeze(0) + 1e-3 * torch.randn(1, n, 3, generator=gen)
+    g = g.to(DEV)
+    torch.manual_seed(0)
+    model = EncodeProcessDecodeMultiScale(10, 7, hidden_size=128, process_steps=10, coarse_process_steps=0, node_out_dim=3,
+                                          attention=False, with_mat_params=False, sample_ratio=0.0, time_dim=1,
+                                          device=DEV).to(DEV)
+    total, ux, uy, ph = model.loss(g)
+    total.backward()
+    grads = [p.grad.clone() for p in model.parameters()]
+    assert all(torch.isfinite(x).all() for x in grads)
+    # (1) the same loss from the inference kernels (statistics now hold the same data twice: same mean / std)
+    with torch.no_grad():
+        delta = model.forward(g)                                             # [1, N, 3] normalised prediction
+        tgt = model.output_normalizer(g["target"] - torch.cat([g["world_pos"], g["phi"]], -1), accumulate=False)
+        err = (delta - tgt) ** 2
+        nt = g["node_type"]
+        comps = [(err[:, nt[:, k + 1] != 1, k].sum(dim=1)).mean() for k in range(3)]
+        ref_total = comps[0] + comps[1] + comps[2]
+    assert abs(float(total.detach()) - float(ref_total)) <= 2e-5 * abs(float(ref_total)), (float(total.detach()), float(ref_total))
+    # (2) directional derivative; the direction scales with each tensor so that every layer takes part
+    gen = torch.Generator(device=DEV).manual_seed(5)
+    direction = [torch.randn(p.shape, device=DEV, generator=gen) * (p.detach().abs().mean() + 1e-3) for p in model.parameters()]
+    analytic = sum(float((gr.double() * d.double()).sum()) for gr, d in zip(grads, direction))
+    eps = 2e-3
+    vals = []
+    with torch.no_grad():
+        for sign in (1.0, -1.0):
+            for p, d in zip(model.parameters(), direction):
+                p.add_(d, alpha=sign * eps)
+            vals.append(float(model.loss(g)[0]))
+            for p, d in zip(model.parameters(), direction):
+                p.sub_(d, alpha=sign * eps)
+    numeric = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(numeric - analytic) <= 3e-2 * abs(analytic), (numeric, analytic, vals)
