@@ -1321,6 +1321,28 @@ __global__ void norm_update_kernel(float* acc_sum, float* acc_sumsq, const doubl
     mean_std[F + k] = sqrtf(var + eps);
 }
 
+// The same update with the row count kept in device memory (count += add), for callers that replay
+// a captured launch sequence and so cannot pass a new scalar per step.
+__global__ void norm_update_counted_kernel(float* acc_sum, float* acc_sumsq, const double* sums, int F, long long* count,
+                                           long long add, float eps, float* mean_std) {
+    const int k = threadIdx.x;
+    const long long c = *count + add;
+    const float safe_count = (float)(c > 1 ? c : 1);
+    if (k < F) {
+        float s = acc_sum[k], q = acc_sumsq[k];
+        if (sums) {
+            s += (float)sums[k]; q += (float)sums[F + k];
+            acc_sum[k] = s; acc_sumsq[k] = q;
+        }
+        const float mean = s / safe_count;
+        const float var = fmaxf(q / safe_count - mean * mean, 0.f);
+        mean_std[k] = mean;
+        mean_std[F + k] = sqrtf(var + eps);
+    }
+    __syncthreads();                       // every lane has read the old count
+    if (k == 0 && add) *count = c;
+}
+
 __global__ void normalize_kernel(const float* __restrict__ x, const float* __restrict__ mean_std,
                                  float* __restrict__ out, long long total, int F, bool inverse) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -1509,6 +1531,16 @@ extern "C" int mgn_norm_update(float* acc_sum, float* acc_sumsq, const double* s
     hipLaunchKernelGGL(norm_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc_sum, acc_sumsq, sums,
                        (int)n_feat, safe, eps, mean_std);
     return check_launch("mgn_norm_update");
+}
+
+extern "C" int mgn_norm_update_counted(float* acc_sum, float* acc_sumsq, const double* sums, int32_t n_feat,
+                                       int64_t* count_dev, int64_t add_rows, float eps, float* mean_std, void* stream) {
+    MGN_REQUIRE(acc_sum && acc_sumsq && mean_std && count_dev && n_feat > 0 && n_feat <= 64 && add_rows >= 0,
+                "mgn_norm_update_counted");
+    MGN_REQUIRE(sums || add_rows == 0, "mgn_norm_update_counted");
+    hipLaunchKernelGGL(norm_update_counted_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, acc_sum, acc_sumsq, sums,
+                       (int)n_feat, (long long*)count_dev, (long long)add_rows, eps, mean_std);
+    return check_launch("mgn_norm_update_counted");
 }
 
 extern "C" int mgn_encode(const float* feat, int32_t n_feat, const float* mean_std, const mgn_mlp* enc, float* out,

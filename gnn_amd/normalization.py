@@ -62,6 +62,23 @@ class Normalizer(nn.Module):
         self._device = device
         return self
 
+    def use_device_count(self, on: bool = True):
+        """Keeps a copy of ``_acc_count`` in device memory and lets the update kernel advance it, so
+        that a captured (HIP graph) launch sequence stays valid from step to step.  ``_acc_count``
+        itself is still advanced on the host by every call that goes through :meth:`stats_for`; a
+        caller that replays captured launches advances it with :meth:`count_replayed`."""
+        w = self._work()
+        if on:
+            w["count_dev"] = torch.tensor([self._acc_count], dtype=torch.int64, device=self._acc_sum.device)
+        else:
+            w.pop("count_dev", None)
+        return self
+
+    def count_replayed(self, rows: int):
+        """Host bookkeeping for one replay of a captured accumulating call (core/normalization.py:36-37)."""
+        self._acc_count += int(rows)
+        self._num_accumulations += 1
+
     def _rows_view(self, batched_data: torch.Tensor) -> torch.Tensor:
         """[B, n, F] -> [n, B*F] rows whose column sums are the reference's sum over dim 1."""
         b, n, f = batched_data.shape
@@ -82,7 +99,7 @@ class Normalizer(nn.Module):
         return the global row count."""
         self._require_device()
         w = self._work()
-        sums = None
+        sums, added = None, 0
         if accumulate and self._num_accumulations < self._max_accumulations:
             n, bf = rows2d.shape
             need = ops.feature_sums_scratch_bytes(n, bf)
@@ -94,7 +111,12 @@ class Normalizer(nn.Module):
                 n = int(partial_sums_hook(sums))
             self._acc_count += n
             self._num_accumulations += 1
-        ops.norm_update(self._acc_sum, self._acc_sum_squared, sums, self._acc_count, self._std_epsilon, w["mean_std"])
+            added = n
+        if w.get("count_dev") is not None:
+            ops.norm_update_counted(self._acc_sum, self._acc_sum_squared, sums, w["count_dev"], added, self._std_epsilon,
+                                    w["mean_std"])
+        else:
+            ops.norm_update(self._acc_sum, self._acc_sum_squared, sums, self._acc_count, self._std_epsilon, w["mean_std"])
         return w["mean_std"]
 
     # ----------------------------------------------------------------- reference API

@@ -227,6 +227,16 @@ def norm_update(acc_sum, acc_sumsq, sums, count: int, eps: float, mean_std):
     _lib.check(rc, "mgn_norm_update")
 
 
+def norm_update_counted(acc_sum, acc_sumsq, sums, count_dev, add_rows: int, eps: float, mean_std):
+    f = acc_sum.numel()
+    rc = _lib.lib().mgn_norm_update_counted(_dev(acc_sum, torch.float32, None, "acc_sum"),
+                                            _dev(acc_sumsq, torch.float32, None, "acc_sumsq"),
+                                            _opt(sums, torch.float64, (2 * f,), "sums"), f,
+                                            _dev(count_dev, torch.int64, (1,), "count_dev"), int(add_rows), float(eps),
+                                            _dev(mean_std, torch.float32, (2 * f,), "mean_std"), _stream())
+    _lib.check(rc, "mgn_norm_update_counted")
+
+
 def normalize(x2d, mean_std, out, inverse: bool = False):
     m, f = x2d.shape
     rc = _lib.lib().mgn_normalize(_dev(x2d, torch.float32, (m, f), "x"), _dev(mean_std, torch.float32, (2 * f,), "mean_std"),

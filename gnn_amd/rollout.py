@@ -7,17 +7,93 @@ swaps device pointers.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .graph import MeshGraph, batch_graphs, unbatch_nodes
 
+GRAPH_MAX_NODES = 8192          # below this a step is bound by host launch overhead (measured: 561 nodes 0.73 -> 0.53 ms per step; at 36k nodes replay is slower than eager launches)
 
-def rollout(model, data, progress: bool = False, reorder=None):
+
+def _wants_graph(model, first, use_graph):
+    if use_graph is None:
+        env = os.environ.get("MGN_ROLLOUT_GRAPH", "")
+        use_graph = first["mesh_pos"].shape[0] <= GRAPH_MAX_NODES if env == "" else env != "0"
+    return bool(use_graph) and model.__dict__.get("halo") is None and torch.device(model.device).type == "cuda"
+
+
+class _StepGraph:
+    """One rollout step -- ``predict`` plus the state feedback -- captured as a HIP graph.
+
+    The step's ~45 launches cost more host time than GPU time on a small mesh; replaying the
+    captured sequence is one launch.  What changes from step to step lives in fixed device
+    buffers: the state (fed back inside the graph), the swelling window (copied in before each
+    replay) and the normalisers' row counts (``Normalizer.use_device_count``)."""
+
+    def __init__(self, model, cur):
+        self.model, self.cur = model, cur
+        self.norms = (model.node_features_normalizer, model.edge_features_normalizer, model.output_normalizer)
+        for nr in self.norms:
+            nr.use_device_count(True)
+        self.accumulating = [nr._num_accumulations < nr._max_accumulations for nr in self.norms[:2]]
+        state = self._snapshot()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):             # a real pass: creates every lazily made buffer outside the capture
+            self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        self._restore(state)
+        counts = [(nr._acc_count, nr._num_accumulations) for nr in self.norms]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.pred = self._body()
+        self.rows_added = [nr._acc_count - c for nr, (c, _) in zip(self.norms, counts)]
+        for nr, (c, k) in zip(self.norms, counts):   # the capture ran the host bookkeeping once without executing
+            nr._acc_count, nr._num_accumulations = c, k
+
+    def _body(self):
+        pred = self.model.predict(self.cur)
+        last = pred[-1]
+        self.cur["world_pos"].copy_(last[:, :2])
+        self.cur["phi"].copy_(last[:, 2:])
+        return pred
+
+    def _snapshot(self):
+        norms = [(nr._acc_sum.clone(), nr._acc_sum_squared.clone(), nr._acc_count, nr._num_accumulations) for nr in self.norms]
+        return norms, self.cur["world_pos"].clone(), self.cur["phi"].clone()
+
+    def _restore(self, state):
+        norms, world, phi = state
+        for nr, (s1, s2, cnt, num) in zip(self.norms, norms):
+            nr._acc_sum.copy_(s1); nr._acc_sum_squared.copy_(s2)
+            nr._acc_count, nr._num_accumulations = cnt, num
+            nr.use_device_count(True)               # device copy of the count back in step
+        self.cur["world_pos"].copy_(world); self.cur["phi"].copy_(phi)
+
+    def valid(self) -> bool:
+        """The captured sequence accumulates (or not) as it did at capture time."""
+        return self.accumulating == [nr._num_accumulations < nr._max_accumulations for nr in self.norms[:2]]
+
+    def step(self):
+        self.graph.replay()
+        for nr, rows, acc in zip(self.norms[:2], self.rows_added[:2], self.accumulating):
+            if acc:
+                nr.count_replayed(rows)
+        return self.pred
+
+    def close(self):
+        for nr in self.norms:
+            nr.use_device_count(False)
+
+
+def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
     """``reorder``: None, or "rcm" / "morton" to renumber the nodes for locality before the
     first step (meshes whose ids do not follow the geometry); every returned tensor stays in
-    the order of ``data``."""
+    the order of ``data``.  ``use_graph``: replay each step as one captured HIP graph (default:
+    meshes up to ``GRAPH_MAX_NODES`` nodes; ``MGN_ROLLOUT_GRAPH=0/1`` overrides the default)."""
     if reorder is not None:
-        return _rollout_reordered(model, data, progress, reorder)
+        return _rollout_reordered(model, data, progress, reorder, use_graph)
     device = model.device
     time_dim = model.time_dim
     n_frames = len(data)
@@ -29,20 +105,32 @@ def rollout(model, data, progress: bool = False, reorder=None):
         sched = torch.stack([data[t]["swelling_phi"] for t in range(n_frames)]
                             + [torch.zeros_like(first["swelling_phi"])] * time_dim).to(device)
         cur = MeshGraph(**dict(static.items()))
-        cur["world_pos"] = first["world_pos"].to(device).clone()
-        cur["phi"] = first["phi"].to(device).clone()
+        cur["world_pos"] = first["world_pos"].to(device, torch.float32).clone()
+        cur["phi"] = first["phi"].to(device, torch.float32).clone()
         preds = [torch.cat([cur["world_pos"], cur["phi"]], dim=-1).unsqueeze(0)]
         steps = range(0, n_frames, time_dim)
         if progress:
             from tqdm import tqdm
             steps = tqdm(steps, desc="Rollout")
-        for t in steps:
-            cur["swelling_phi"] = sched[t: t + time_dim + 1].T.contiguous()
-            pred = model.predict(cur)
-            last = pred[-1]
-            cur["world_pos"] = last[:, :2].contiguous()
-            cur["phi"] = last[:, 2:].contiguous()
-            preds.append(pred)
+        captured = None
+        if _wants_graph(model, first, use_graph) and n_frames > 2 * time_dim:
+            cur["swelling_phi"] = sched[0: time_dim + 1].T.contiguous().to(torch.float32)
+            captured = _StepGraph(model, cur)
+        try:
+            for t in steps:
+                if captured is not None and captured.valid():
+                    cur["swelling_phi"].copy_(sched[t: t + time_dim + 1].T)
+                    preds.append(captured.step().clone())
+                    continue
+                cur["swelling_phi"] = sched[t: t + time_dim + 1].T.contiguous()
+                pred = model.predict(cur)
+                last = pred[-1]
+                cur["world_pos"] = last[:, :2].contiguous()
+                cur["phi"] = last[:, 2:].contiguous()
+                preds.append(pred)
+        finally:
+            if captured is not None:
+                captured.close()
         rollout_preds = torch.cat(preds, dim=0)[:n_frames]
         rollout_gts = torch.stack([torch.cat([data[t]["world_pos"], data[t]["phi"]], dim=-1)
                                    for t in range(n_frames)]).to(device)
@@ -66,11 +154,11 @@ def rollout(model, data, progress: bool = False, reorder=None):
     }
 
 
-def _rollout_reordered(model, data, progress, method):
+def _rollout_reordered(model, data, progress, method, use_graph=None):
     from . import reorder as R
     order = R.node_order(data[0], method)
     edges = R.permute_frame({"mesh_pos": data[0]["mesh_pos"], "edge_index": data[0]["edge_index"]}, order)["edge_index"]
-    res = rollout(model, [R.permute_frame(fr, order, relabelled_edges=edges) for fr in data], progress)
+    res = rollout(model, [R.permute_frame(fr, order, relabelled_edges=edges) for fr in data], progress, use_graph=use_graph)
     for k in ("pred", "gt", "swelling_phi"):
         res[k] = R.restore_nodes(res[k], order, dim=1)
     first = data[0]

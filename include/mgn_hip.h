@@ -131,6 +131,14 @@ int mgn_feature_sums(const float* feat, int64_t rows, int32_t n_feat, double* su
 int mgn_norm_update(float* acc_sum, float* acc_sumsq, const double* sums, int32_t n_feat,
                     int64_t count, float eps, float* mean_std /*[2F]*/, void* stream);
 
+/* mgn_norm_update with the accumulated row count resident on the device: *count_dev += add_rows, then
+ * the statistics as above with the new count.  For launch sequences that are captured once and
+ * replayed (HIP graphs), where a per-call scalar would be frozen at capture time; the caller keeps
+ * its host-side count (core/normalization.py:36) in step.  add_rows = 0 with sums = NULL only
+ * recomputes mean_std. */
+int mgn_norm_update_counted(float* acc_sum, float* acc_sumsq, const double* sums, int32_t n_feat, int64_t* count_dev,
+                            int64_t add_rows, float eps, float* mean_std /*[2F]*/, void* stream);
+
 /* Normalizer.forward / inverse applied to rows (core/normalization.py:24, :26-28):
  * out = (x - mean) / std, or with inverse != 0: out = std * x + mean.  x is [rows][F].  */
 int mgn_normalize(const float* x, const float* mean_std /*[2F]*/, float* out, int64_t rows, int32_t n_feat,

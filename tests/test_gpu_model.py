@@ -326,3 +326,40 @@ def test_rollout_with_locality_reordering(method):
     assert torch.equal(fast["gt"], plain["gt"]) and torch.equal(fast["swelling_phi"], plain["swelling_phi"])
     assert rel_l2(fast["pred"], plain["pred"]) < 1e-5, rel_l2(fast["pred"], plain["pred"])
     assert torch.equal(fast["mesh_pos"], shuffled[0]["mesh_pos"])
+
+
+@pytest.mark.parametrize("time_dim", [1, 2])
+def test_graph_replayed_rollout_equals_eager(time_dim):
+    """The rollout that replays one captured HIP graph per step against the eager launch sequence,
+    with statistics that are still accumulating (their row counts advance in device memory during
+    replay): predictions bit-identical, normaliser state identical at the end."""
+    import gnn_amd
+    from gnn_amd.rollout import rollout
+    cfg = O.OracleConfig(process_steps=3, time_dim=time_dim, node_in_dim=9 + time_dim)
+    sd = O.init_state_dict(cfg, 8)
+    frames = gnn_amd.synthetic_frames(14, 9, n_frames=13, seed=3)
+    outs = []
+    for use_graph in (False, True):
+        model = build_model(cfg, sd)
+        res = rollout(model, frames, use_graph=use_graph)
+        norms = (model.node_features_normalizer, model.edge_features_normalizer, model.output_normalizer)
+        outs.append((res["pred"], [(nr._acc_sum.clone(), nr._acc_sum_squared.clone(), nr._acc_count, nr._num_accumulations)
+                                   for nr in norms]))
+        # the device-side counters are gone again: a later eager call uses the host count
+        assert all(nr._work().get("count_dev") is None for nr in norms)
+        again = model.predict(frames_to_window(frames, 0, time_dim))
+        assert torch.isfinite(again).all()
+    (pa, na), (pb, nb) = outs
+    assert pa.shape == pb.shape and torch.equal(pa, pb)
+    for (s1, q1, c1, k1), (s2, q2, c2, k2) in zip(na, nb):
+        assert torch.equal(s1, s2) and torch.equal(q1, q2) and c1 == c2 and k1 == k2
+    assert na[0][3] == (13 + time_dim - 1) // time_dim
+
+
+def frames_to_window(frames, t, time_dim):
+    """Frame t with the swelling window [N, time_dim + 1] the model expects."""
+    from gnn_amd.graph import MeshGraph
+    g = MeshGraph(**dict(frames[t].items()))
+    sw = [frames[min(t + k, len(frames) - 1)]["swelling_phi"] for k in range(time_dim + 1)]
+    g["swelling_phi"] = torch.stack(sw, dim=1)
+    return g.to(DEV)
