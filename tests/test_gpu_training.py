@@ -330,3 +330,40 @@ def test_full_size_training_step_properties():
                 p.sub_(d, alpha=sign * eps)
     numeric = (vals[0] - vals[1]) / (2 * eps)
     assert abs(numeric - analytic) <= 3e-2 * abs(analytic), (numeric, analytic, vals)
+
+
+def test_loss_grads_irregular_graph():
+    """Gradients on a directed, asymmetric graph with isolated nodes and a hub whose 300 in-edges span
+    several 32-edge tiles (the receiver-segmented sums of the fused edge backward chain across tiles
+    there; the sender-side sums see senders without any edge): against the fp64 oracle with the
+    step's ReLU pattern pinned, and fused against unfused."""
+    from gnn_amd import training
+    cfg = O.OracleConfig(process_steps=2)
+    sd = O.init_state_dict(cfg, 12)
+    g = O.synthetic_graph(20, 15, seed=5, with_target=True)
+    n = g["mesh_pos"].shape[0]
+    gen = torch.Generator().manual_seed(11)
+    e = 2500
+    snd = torch.randint(0, n, (e,), generator=gen)
+    rcv = torch.randint(0, n, (e,), generator=gen)
+    rcv[:300] = 7                                                    # hub
+    iso = torch.tensor([3, 50, 51, 52, n - 1])                       # nodes that neither send nor receive
+    keep = ~(torch.isin(snd, iso) | torch.isin(rcv, iso)) & (snd != rcv)
+    g["edge_index"] = torch.unique(torch.stack([snd[keep], rcv[keep]]), dim=1)
+    model = build_model(cfg, sd).train()
+    norms = O.make_norms(cfg)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ol = O.loss(sdg, cfg, norms, g)
+    ol[0].backward()
+    copy_norms_frozen(model, norms)
+    loss3, grads, masks = gpu_loss_and_grads(model, g)
+    for c in range(3):
+        assert abs(float(loss3[c]) - float(ol[c + 1].detach())) <= 1e-5 * abs(float(ol[c + 1].detach()))
+    _, pinned = pinned_oracle_grads(cfg, sd, norms, g, masks)
+    check_grads(grads, pinned, {k: v.grad for k, v in sdg.items()})
+    gg = graph_to(g, DEV)
+    tgt = model._normalized_target(gg)
+    _, saved = training.forward_saving(model, gg, tgt, fused=False)
+    unfused = training.backward(model, saved, torch.ones(3, device=DEV))
+    worst = max((rel_l2(grads[k], unfused[k].cpu()), k) for k in grads)
+    assert worst[0] < 2e-6, worst
