@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json target): one autoregressive rollout step (`predict`: features ->
+Workload: one autoregressive rollout step (`predict`: features ->
 normalisers -> encoders -> 15 message-passing steps -> decoder -> integrator) on a synthetic
 1000 x 1000-node triangle mesh (1 000 000 nodes, 5 992 002 directed edges), latent 128, fp32,
 seeded random weights, inputs resident in HBM.  With N > 1 every rank keeps that much work: the
