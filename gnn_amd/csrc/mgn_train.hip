@@ -787,367 +787,6 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
     }
 }
 
-// ------------------------------------------------------------------------ edge update backward, two roles
-// The same computation as train_edge_bwd_kernel with two 4-wave roles in one 8-wave workgroup, two
-// waves per SIMD, so that one role's matrix phase runs beside the other's vector / memory phase:
-//   role 0 (producer, tile i):  requests, h1 recomputation, LayerNorm statistics and backward -> g2;
-//                               keeps W0e / W2 as fp16 planes; dgamma / dbeta per lane
-//   role 1 (consumer, tile i-1): dW2 += g2^T h1, db2, g1 = (g2 W2) * (h1 > 0), g1 and dpr to memory,
-//                               stages the next e tile; keeps W2^T as bf16 planes and the dW2 accumulators
-// Four workgroup barriers per iteration (a1, b1, b2, b3) separate the hand-overs:
-//   segment 1  P: requests, product 1, h1 -> h1P, H1T[i&1], hm[i&1]      C: dW2, db2 from G2T, H1T[(i-1)&1]
-//   segment 2  P: product 2, statistics                                   C: g1 product from G2P -> Ot (= H1T[(i-1)&1])
-//   segment 3  P: xhat, upstream gradient, row sums                       C: scan, row reads
-//   segment 4  P: g2 -> G2P, G2T                                          C: g1 / dpr stores, next e tile -> elP
-constexpr int TK8 = TM;                     // unpadded transposed planes: 64 B per feature row
-constexpr int TPLANE8 = H * TK8;
-__device__ __forceinline__ int tpos8(int f, int blk) { return f * TK8 + 8 * (blk ^ ((f >> 2) & 3)); }
-
-__device__ __forceinline__ void tstore_acc8(unsigned short* tp, const f32x16& v, int w, int j, int h) {
-    const bool odd = j & 1;
-    const int r0 = j & ~1;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const float o0 = swap_lane1(v[2 * p]), o1 = swap_lane1(v[2 * p + 1]);
-        const float mine = odd ? v[2 * p + 1] : v[2 * p], other = odd ? o1 : o0;
-        unsigned ha, ma, la, hb, mb, lb;
-        split3(odd ? other : mine, ha, ma, la);      // row r0
-        split3(odd ? mine : other, hb, mb, lb);      // row r0 + 1
-        const int g = p >> 1, k = 2 * (p & 1) + (odd ? 1 : 0);
-        const int f = 32 * w + 8 * g + 4 * h + k;
-        unsigned* d = (unsigned*)(tp + tpos8(f, r0 >> 3) + (r0 & 7));
-        d[0] = pack_hi16(ha, hb);
-        d[TPLANE8 / 2] = pack_hi16(ma, mb);
-        d[TPLANE8] = pack_hi16(la, lb);
-    }
-}
-
-// sum of the eight bf16 values of an operand fragment
-__device__ __forceinline__ float sum_bf16x8(const u32x4 v) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += __uint_as_float(v[i] << 16) + __uint_as_float(v[i] & 0xFFFF0000u);
-    return s;
-}
-
-__global__ __launch_bounds__(2 * NT, 1) void train_edge_bwd8_kernel(EdgeBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short elP[2 * PLH];            // e tile, fp16 planes
-    __shared__ __attribute__((aligned(16))) unsigned short h1P[2 * PLH];            // h1 tile, fp16 planes
-    __shared__ __attribute__((aligned(16))) unsigned short H1T[2][3 * TPLANE8];     // h1 tile, transposed bf16 planes (x2); then Ot
-    __shared__ __attribute__((aligned(16))) unsigned short G2P[3 * PLANE];          // g2 tile, row-major bf16 planes
-    __shared__ __attribute__((aligned(16))) unsigned short G2T[3 * TPLANE8];        // g2 tile, transposed bf16 planes
-    __shared__ __attribute__((aligned(16))) float vec[2][H];                        // W_SCALE * b2, gamma
-    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
-    __shared__ __attribute__((aligned(16))) float red2[LN_RED_FLOATS];
-    __shared__ float cout[H], tcarry[H];
-    __shared__ unsigned hm[2][NT];                                                  // h1 > 0 per accumulator register
-    __shared__ int srange[2];
-    static_assert(sizeof(H1T[0]) >= sizeof(float) * tile_floats(H / 4), "Ot must fit into one H1T buffer");
-    static_assert(sizeof(G2P) >= sizeof(float) * tile_floats(H / 4), "the final reduction tile must fit into G2P");
-
-    const int role = threadIdx.x >> 8;
-    const int t = threadIdx.x & (NT - 1), lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
-    if (role == 0 && t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; tcarry[t] = 0.f; }
-    if (threadIdx.x == 0) {
-        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long first = a.rowptr[0];
-        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
-        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
-        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
-    }
-    __syncthreads();
-    const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
-    const int last = e1 - e0 - 1;                    // row offsets are relative to e0 and clamped to [0, last]
-    const int ntiles = e1 > e0 ? (last + TM) / TM : 0;
-    const float* el_g = a.el + (size_t)e0 * H;
-    const int* rcv_g = a.recv + e0;
-    const int srow = t >> 5, sq = t & 31;            // row map: rows srow + 8*it, 16-byte chunk sq
-    float* p = a.partial + (size_t)blockIdx.x * PARTIAL_E;
-    float* Ft = (float*)G2P;                         // fp32 tile for the final column sums
-
-    if (role == 0) {
-        // ================================================================== producer
-        WPlanesH<8> wa, wb;
-        load_wplanes_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
-        load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
-        f32x16 dgam = zero16(), dbet = zero16();
-        const float* ge_g = a.ge ? a.ge + (size_t)e0 * H : nullptr;
-        const int* snd_g = a.sender + e0;
-        int s_cur = 0, r_cur = 0;
-        if (ntiles > 0) { s_cur = snd_g[min(j, last)]; r_cur = rcv_g[min(j, last)]; }
-        __syncthreads();                                                     // e tile 0 staged by the consumer
-        STAMP_DECL
-        for (int i = 0; i <= ntiles; ++i) {
-            STAMP(0);
-            const bool active = i < ntiles;
-            const int rel = i * TM;
-            const bool valid = active && j < min(TM, last + 1 - rel);
-            f32x4 ye[4], ya[4];
-            f32x16 acc, xh, g2;
-            float rstd = 0.f;
-            if (active) {
-                f32x4 gs[4], gr[4];
-                const unsigned so = (unsigned)s_cur * H + 32 * w + 4 * h, ro = (unsigned)r_cur * H + 32 * w + 4 * h;
-                const unsigned eo = (unsigned)min(rel + j, last) * H + 32 * w + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { gs[g] = *(const f32x4*)(a.ps + so + 8 * g); gr[g] = *(const f32x4*)(a.pr + ro + 8 * g); }
-                const int s_nxt = snd_g[min(rel + TM + j, last)], r_nxt = rcv_g[min(rel + TM + j, last)];
-                acc = zero16();
-                acc = wave_gemm_h<0, 8, 8>(elP, PLH, PKH, 0, wa, j, h, acc);
-                unsigned hmask = 0;
-                {
-                    f32x16 h1;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 v;
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            v[k] = fmaxf(fmaf(acc[4 * g + k], W_UNSCALE, gs[g][k] + gr[g][k]), 0.f);
-                            h1[4 * g + k] = v[k];
-                            hmask |= v[k] > 0.f ? 1u << (4 * g + k) : 0u;
-                        }
-                        hplanes_store4(h1P, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
-                    }
-                    tstore_acc8(H1T[i & 1], h1, w, j, h);
-                }
-                hm[i & 1][t] = hmask;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {                                // upstream gradient rows, used after b1
-                    ya[g] = *(const f32x4*)(a.gaggr + ro + 8 * g);
-                    ye[g] = ge_g ? *(const f32x4*)(ge_g + eo + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                s_cur = s_nxt; r_cur = r_nxt;
-            }
-            STAMP(1);
-            __syncthreads();                                                 // (a1) h1 planes complete
-            STAMP(2);
-            if (active) {
-                acc = acc_from_vec(vec[0], w, h);
-                acc = wave_gemm_h<0, 8, 8>(h1P, PLH, PKH, 0, wb, j, h, acc);
-                acc = relu16(acc);                                           // W_SCALE * v
-                ln_local_stats_rows(acc, red, w, j, h);
-            }
-            STAMP(3);
-            __syncthreads();                                                 // (b1) statistics exchanged
-            STAMP(4);
-            if (active) {
-                const f32x4 ma = *(const f32x4*)(red + j * LN_RED_LD), mb = *(const f32x4*)(red + j * LN_RED_LD + 4);
-                const f32x4 qa = *(const f32x4*)(red + j * LN_RED_LD + 8), qb = *(const f32x4*)(red + j * LN_RED_LD + 12);
-                const float mean = (((ma[0] + ma[1]) + (ma[2] + ma[3])) + ((mb[0] + mb[1]) + (mb[2] + mb[3]))) * 0.125f;
-                const float m2 = ((qa[0] + qa[1]) + (qa[2] + qa[3])) + ((qb[0] + qb[1]) + (qb[2] + qb[3]));
-                const f32x4 da = ma - mean, db = mb - mean;
-                const float between = ((da[0] * da[0] + da[1] * da[1]) + (da[2] * da[2] + da[3] * da[3])) +
-                                      ((db[0] * db[0] + db[1] * db[1]) + (db[2] * db[2] + db[3] * db[3]));
-                const float var = (m2 + 16.0f * between) * (1.0f / H);
-                rstd = __builtin_amdgcn_rsqf(var + LN_EPS * W_SCALE * W_SCALE);
-                const float shift = -mean * rstd;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) xh[q] = fmaf(acc[q], rstd, shift);
-                float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 ga = *(const f32x4*)(vec[1] + 32 * w + 8 * g + 4 * h);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int q = 4 * g + k;
-                        const float gy = valid ? ye[g][k] + ya[g][k] : 0.f;
-                        dbet[q] += gy;
-                        dgam[q] = fmaf(gy, xh[q], dgam[q]);
-                        const float ghv = gy * ga[k];
-                        g2[q] = ghv;
-                        s1 += ghv;
-                        s2 = fmaf(ghv, xh[q], s2);
-                    }
-                }
-                red2[j * LN_RED_LD + 2 * w + h] = s1;
-                red2[j * LN_RED_LD + 8 + 2 * w + h] = s2;
-            }
-            STAMP(5);
-            __syncthreads();                                                 // (b2) row sums exchanged
-            STAMP(6);
-            if (active) {
-                const f32x4 pa = *(const f32x4*)(red2 + j * LN_RED_LD), pb = *(const f32x4*)(red2 + j * LN_RED_LD + 4);
-                const f32x4 qa = *(const f32x4*)(red2 + j * LN_RED_LD + 8), qb = *(const f32x4*)(red2 + j * LN_RED_LD + 12);
-                const float m1 = (((pa[0] + pa[1]) + (pa[2] + pa[3])) + ((pb[0] + pb[1]) + (pb[2] + pb[3]))) * (1.0f / H);
-                const float m2 = (((qa[0] + qa[1]) + (qa[2] + qa[3])) + ((qb[0] + qb[1]) + (qb[2] + qb[3]))) * (1.0f / H);
-                const float rs = rstd * W_SCALE;
-#pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    const float gv = rs * (g2[q] - m1 - xh[q] * m2);
-                    g2[q] = acc[q] > 0.f ? gv : 0.f;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    planes_store4(G2P, j, 32 * w + 8 * g + 4 * h, f32x4{g2[4 * g], g2[4 * g + 1], g2[4 * g + 2], g2[4 * g + 3]});
-                tstore_acc8(G2T, g2, w, j, h);
-            }
-            STAMP(7);
-            __syncthreads();                                                 // (b3) g2 planes complete
-        }
-        STAMP_FLUSH(w == 0 ? 0 : -1)
-        // column sums of the per-lane accumulators (the consumer takes part in the barriers)
-        acc_to_tile(Ft, dgam, w, j, h);
-        __syncthreads();
-        if (t < H) {
-            float sum = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < TM; ++r) sum += Ft[r * (H + 4) + t];
-            p[H * H + H + t] = sum;
-        }
-        __syncthreads();
-        acc_to_tile(Ft, dbet, w, j, h);
-        __syncthreads();
-        if (t < H) {
-            float sum = 0.f;
-#pragma unroll 8
-            for (int r = 0; r < TM; ++r) sum += Ft[r * (H + 4) + t];
-            p[H * H + 2 * H + t] = sum;
-        }
-    } else {
-        // ================================================================== consumer
-        WPlanes32 w2t;
-        load_wplanes32_t(w2t, a.w1, H, 32 * w + j, h);
-        f32x16 dw2[4];
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) dw2[kb] = zero16();
-        float db2 = 0.f;
-        float* g1_g = a.g1 + (size_t)e0 * H;
-        const int sc = t & (H - 1);
-        const int sg = __builtin_amdgcn_readfirstlane(t >> 7);
-        f32x4 pre[4];
-        if (ntiles > 0) {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) pre[it] = *(const f32x4*)(el_g + (unsigned)(min(srow + 8 * it, last) * H + 4 * sq));
-#pragma unroll
-            for (int it = 0; it < 4; ++it) hplanes_store4(elP, PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);
-        }
-        int ra = 0, rb = -1;
-        __syncthreads();                                                     // e tile 0 staged
-        STAMP_DECL
-        for (int i = 0; i <= ntiles; ++i) {
-            STAMP(0);
-            const int k = i - 1;
-            const bool active = k >= 0;
-            const int rel = k * TM;
-            const int nvalid = active ? min(TM, last + 1 - rel) : 0;
-            const bool more = i + 1 < ntiles;                                // e tile i + 1 is staged in segment 4
-            if (more) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it)
-                    pre[it] = *(const f32x4*)(el_g + (unsigned)(min((i + 1) * TM + srow + 8 * it, last) * H + 4 * sq));
-            }
-            if (active) {
-                ra = rcv_g[min(rel + j, last)];
-                rb = (rel + j + 1 <= last) ? rcv_g[rel + j + 1] : -1;
-                const unsigned short* h1t = H1T[k & 1];
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const int blk = 2 * s + h;
-                    const unsigned short* gp = G2T + tpos8(32 * w + j, blk);
-                    const u32x4 gh = *(const u32x4*)gp, gm = *(const u32x4*)(gp + TPLANE8), gl = *(const u32x4*)(gp + 2 * TPLANE8);
-                    db2 += (sum_bf16x8(gl) + sum_bf16x8(gm)) + sum_bf16x8(gh);
-#pragma unroll
-                    for (int kp = 0; kp < 2; ++kp) {
-                        u32x4 ah[2], am[2], al[2];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const unsigned short* ap = h1t + tpos8(32 * (2 * kp + q) + j, blk);
-                            ah[q] = *(const u32x4*)ap; am[q] = *(const u32x4*)(ap + TPLANE8); al[q] = *(const u32x4*)(ap + 2 * TPLANE8);
-                        }
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gl, ah[q], dw2[2 * kp + q]);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, al[q], dw2[2 * kp + q]);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gm, am[q], dw2[2 * kp + q]);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gm, ah[q], dw2[2 * kp + q]);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, am[q], dw2[2 * kp + q]);
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, ah[q], dw2[2 * kp + q]);
-                    }
-                }
-            }
-            STAMP(1);
-            __syncthreads();                                                 // (a1) every wave is done with H1T[k&1]
-            STAMP(2);
-            float* Ot = (float*)H1T[k & 1];
-            if (active) {
-                f32x16 acc = zero16();
-                acc = wave_gemm3_32<0, 8>(G2P, w2t, j, h, acc);
-                const unsigned hmask = hm[k & 1][t];
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[q] = (hmask >> q) & 1u ? acc[q] : 0.f;
-                acc_to_tile(Ot, acc, w, j, h);
-            }
-            STAMP(3);
-            __syncthreads();                                                 // (b1) g1 tile complete
-            STAMP(4);
-            unsigned mask = 0, gmask = 0;
-            float xr[16], part = 0.f, cin = 0.f;
-            f32x4 y[4];
-            if (active) {
-                mask = (unsigned)__ballot(j < nvalid && ra != rb);           // bit r: row r ends its segment
-                gmask = (mask >> (16 * sg)) & 0xFFFFu;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xr[r] = Ot[(16 * sg + r) * (H + 4) + sc];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    part += xr[r];
-                    xr[r] = part;
-                    if ((gmask >> r) & 1u) part = 0.f;
-                }
-                cin = tcarry[sc];
-                if (sg == 0) cout[sc] = gmask ? part : cin + part;
-#pragma unroll
-                for (int it = 0; it < 4; ++it) y[it] = *(const f32x4*)(Ot + toff(srow + 8 * it, sq, H / 4));
-            }
-            STAMP(5);
-            __syncthreads();                                                 // (b2) cout visible
-            STAMP(6);
-            if (more) {
-#pragma unroll
-                for (int it = 0; it < 4; ++it) hplanes_store4(elP, PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);
-            }
-            if (active) {
-                if (sg == 1) cin = cout[sc];
-                float* go = g1_g + (unsigned)(rel * H);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int row = srow + 8 * it;
-                    if (row < nvalid) *(f32x4*)(go + (unsigned)(row * H + 4 * sq)) = y[it];
-                }
-                bool open = true;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if ((gmask >> r) & 1u) {
-                        const int node = __builtin_amdgcn_readlane(ra, 16 * sg + r);
-                        a.dpr[(unsigned)(node * H + sc)] = open ? cin + xr[r] : xr[r];
-                        open = false;
-                    }
-                }
-                if (sg == 1) tcarry[sc] = gmask ? part : cin + part;
-            }
-            STAMP(7);
-            __syncthreads();                                                 // (b3) next e tile staged, tcarry settled
-        }
-        STAMP_FLUSH(w == 0 ? 1 : -1)
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int f = 32 * w + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                p[f * H + 32 * kb + j] = dw2[kb][reg];
-            }
-        red[h * H + 32 * w + j] = db2;               // the two lane halves hold different rows of the same feature
-        __syncthreads();
-        if (t < H) p[H * H + t] = red[t] + red[H + t];
-        __syncthreads();
-        __syncthreads();
-    }
-}
-
 // out[(i / width) * ld + (i % width)] = sum over blocks of partial[b * stride + offset + i].  Eight
 // independent running sums per thread (blocks b = k mod 8) keep eight loads in flight; they are
 // combined pairwise in a fixed order, so the result does not depend on the launch.
@@ -1396,9 +1035,7 @@ extern "C" int mgn_train_edge_bwd(const float* e_in, const float* g_e, const flo
     EdgeBwdArgs a{e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, ln_w, g1, dpr, (float*)scratch,
                   (int)n_nodes, (int)n_edges};
     const int g = train_grid(n_edges, 1);
-    static const bool one_role = getenv("MGN_EDGE_BWD_4WAVE") != nullptr;     // diagnostic: the single-role kernel
-    if (one_role) hipLaunchKernelGGL(train_edge_bwd_kernel, dim3(g), dim3(NT), 0, s, a);
-    else hipLaunchKernelGGL(train_edge_bwd8_kernel, dim3(g), dim3(2 * NT), 0, s, a);
+    hipLaunchKernelGGL(train_edge_bwd_kernel, dim3(g), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(reduce_partials_kernel, dim3(PARTIAL_W / 64), dim3(64), 0, s, (const float*)scratch, g, PARTIAL_E, 0,
                        PARTIAL_W, H, H, dW1);
     float* outs[3] = {db1, dgamma, dbeta};

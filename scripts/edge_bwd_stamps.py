@@ -46,16 +46,6 @@ for it in range(3):
     lib.mgn_debug_read_train_stamps(buf, 1)
 print("kernel + reductions: %.3f ms" % t0.elapsed_time(t1))
 vals = list(buf)
-if os.environ.get("MGN_EDGE_BWD_4WAVE") is None:
-    names8 = {0: "b3 -> top", 1: "segment 1", 2: "barrier a1", 3: "segment 2", 4: "barrier b1", 5: "segment 3", 6: "barrier b2",
-              7: "segment 4"}
-    nt = (e + 31) // 32
-    for wsel, label in ((0, "producer wave 0"), (1, "consumer wave 0")):
-        tot = sum(vals[wsel * 16: wsel * 16 + 16])
-        print(label, "cycles per tile: %.0f" % (tot / nt))
-        for i in range(8):
-            print("   %-20s %8.0f  %5.1f%%" % (names8[i], vals[wsel * 16 + i] / nt, 100.0 * vals[wsel * 16 + i] / max(tot, 1)))
-    sys.exit(0)
 names = {0: "barrier F -> top", 1: "requests", 2: "product 1", 3: "h1: ReLU, fp16 planes, transposed planes", 4: "barrier B",
          5: "product 2, LN statistics, stage next e tile", 6: "barrier C", 7: "LN: xhat, upstream gradient, row sums", 8: "barrier C2",
          9: "g2, row-major + transposed planes", 10: "barrier D", 11: "dW2 products", 12: "g1 product, mask, -> Ot", 13: "barrier E",
