@@ -374,199 +374,7 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
     }
 }
 
-// The same kernel on the fp16 matrix pipe: two-term fp16 split of every operand, three partial
-// products per k-step (half the matrix instructions, two LDS planes instead of three, a cheaper
-// split).  The second Linear accumulates W_SCALE * (product + bias); LayerNorm is invariant to that
-// factor once its epsilon is scaled by W_SCALE^2, so nothing is multiplied back.
-constexpr int PLH = TM * PKH;
-__global__ __launch_bounds__(NT3, 2) void mp_edge_h_kernel(EdgeArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Xp[2 * PLH];        // staged e_in tile, 2 fp16 planes
-    __shared__ __attribute__((aligned(16))) unsigned short Hp[2][2 * PLH];     // hidden tile, 2 fp16 planes, double buffered
-    __shared__ __attribute__((aligned(16))) float Es[tile_floats(H / 4)];      // pre-residual output tile (fp32)
-    __shared__ __attribute__((aligned(16))) float Gs[tile_floats(H / 4)];      // ps[sender] + pr[receiver] per tile row
-    __shared__ __attribute__((aligned(16))) float vec[3][H];                   // b1, ln_w, ln_b
-    __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
-    __shared__ float cout[H], tcarry[H];
-    __shared__ int srange[2];
-
-    const int t = threadIdx.x, lane = t & 63, role = t >> 8, w = (t >> 6) & 3, t1 = t & 255;
-    const int j = lane & 31, h = lane >> 5;
-
-    if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
-    if (t == 0) {
-        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
-        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
-        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
-        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
-    }
-    __syncthreads();
-    const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
-    if (e0 >= e1) return;
-    const int last = e1 - e0 - 1;                    // row offsets below are relative to e0 and clamped to [0, last]
-    const int ntiles = last / TM + 1;
-    const float* ein_g = a.e_in + (size_t)e0 * H;
-    float* eout_g = a.e_out + (size_t)e0 * H;
-    const int* snd_g = a.sender + e0;
-    const int* rcv_g = a.recv + e0;
-    const int srow = t1 >> 5, sq = t1 & 31;          // row-major map of a role's 256 threads: rows srow + 8*it, chunk sq
-
-    if (role == 0) {
-        // ------------------------------------------------------------------ role 0: first Linear
-        WPlanesH<8> wa;
-        load_wplanes_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
-        f32x4 nx[4];
-        int sid[4], rid[4];                          // sender / receiver of the rows this thread gathers; kept raw so
-                                                     // that nothing waits for these loads in the iteration issuing them
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int r = min(srow + 8 * it, last);
-            nx[it] = *(const f32x4*)(ein_g + (unsigned)(r * H + 4 * sq));
-            sid[it] = snd_g[r]; rid[it] = rcv_g[r];
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) hplanes_store4(Xp, PLH, PKH, srow + 8 * it, 4 * sq, nx[it]);
-        __syncthreads();                                                     // b0: tile 0 staged
-        STAMP_DECL
-        for (int i = 0; i < ntiles + 2; ++i) {
-            STAMP(0);
-            const bool act = i < ntiles;
-            const int rel = i * TM;
-            f32x16 acc;
-            f32x4 ga[4], gb[4];
-            if (act) {
-                // this tile's per-node projections, gathered as whole 512-byte rows (thread = row, chunk);
-                // next tile's rows and ids
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    ga[it] = *(const f32x4*)(a.ps + ((unsigned)sid[it] * H + 4 * sq));
-                    gb[it] = *(const f32x4*)(a.pr + ((unsigned)rid[it] * H + 4 * sq));
-                }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {
-                    const int r = min(rel + TM + srow + 8 * it, last);
-                    nx[it] = *(const f32x4*)(ein_g + (unsigned)(r * H + 4 * sq));
-                    sid[it] = snd_g[r]; rid[it] = rcv_g[r];
-                }
-                STAMP(6);
-                acc = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                acc = wave_gemm_h<0, 4, 8>(Xp, PLH, PKH, 0, wa, j, h, acc);
-            }
-            STAMP(1);
-            __syncthreads();                                                 // bm
-            STAMP(2);
-            if (act) {
-                acc = wave_gemm_h<4, 8, 8>(Xp, PLH, PKH, 0, wa, j, h, acc);
-                // the gathers have had both halves of the product to arrive
-#pragma unroll
-                for (int it = 0; it < 4; ++it) *(f32x4*)(Gs + toff(srow + 8 * it, sq, H / 4)) = ga[it] + gb[it];
-            }
-            STAMP(3);
-            __syncthreads();                                                 // b1: every wave is done reading Xp; Gs complete
-            STAMP(4);
-            if (act) {
-                unsigned short* Hb = Hp[i & 1];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 gg = *(const f32x4*)(Gs + toff(j, 8 * w + 2 * g + h, H / 4));
-                    f32x4 v;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(acc[4 * g + k], W_UNSCALE, gg[k]), 0.f);
-                    hplanes_store4(Hb, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
-                }
-#pragma unroll
-                for (int it = 0; it < 4; ++it) hplanes_store4(Xp, PLH, PKH, srow + 8 * it, 4 * sq, nx[it]);   // tile i+1
-            }
-            STAMP(5);
-            __syncthreads();                                                 // b2
-        }
-        STAMP_FLUSH(w == 0 ? 0 : -1)
-    } else {
-        // ------------------------------------------------------------------ role 1: second Linear
-        WPlanesH<8> wb;
-        load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
-        const int sc = t1 & (H - 1);
-        const int sg = __builtin_amdgcn_readfirstlane(t1 >> 7);     // scan group: rows 16*sg .. 16*sg+15
-        f32x16 acc;
-        f32x4 er[4];                                 // fp32 rows of the tile stored next (residual)
-        int ra = 0, rb = -1;                         // receiver of tile row (lane & 31) and of the row after it
-        float part = 0.f, cin = 0.f, xr[16];
-        unsigned mask = 0, gmask = 0;
-        __syncthreads();                                                     // b0
-        STAMP_DECL
-        for (int i = 0; i < ntiles + 2; ++i) {
-            STAMP(0);
-            const int k = i - 2;                     // tile in its LayerNorm / store stage
-            const int relk = k * TM, nvalid = min(TM, last + 1 - relk);
-            if (k >= 0) {
-                acc = ln_finish_rows(acc, red, w, j, h, vec[1], vec[2], LN_EPS * W_SCALE * W_SCALE);
-                acc_to_tile(Es, acc, w, j, h);
-            }
-            STAMP(1);
-            __syncthreads();                                                 // bm
-            STAMP(2);
-            if (k >= 0) {
-                // segment ends first: this consumes the receiver ids loaded one iteration ago, before
-                // the conditional stores below make the outstanding-load count unknown to the compiler
-                mask = (unsigned)__ballot(j < nvalid && ra != rb);          // bit r: row r ends its segment
-                gmask = (mask >> (16 * sg)) & 0xFFFFu;
-                float* eo = eout_g + (unsigned)(relk * H);
-#pragma unroll
-                for (int it = 0; it < 4; ++it) {     // residual + coalesced store
-                    const int row = srow + 8 * it;
-                    const f32x4 y = *(const f32x4*)(Es + toff(row, sq, H / 4));
-                    if (row < nvalid) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y + er[it];
-                }
-                // receiver-segmented sum: thread (column sc, group sg) scans rows 16sg .. 16sg+15 in
-                // order; xr[r] = sum of the rows since the last segment end before r
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xr[r] = Es[(16 * sg + r) * (H + 4) + sc];
-                part = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    part += xr[r];
-                    xr[r] = part;
-                    if ((gmask >> r) & 1u) part = 0.f;
-                }
-                if (sg == 0) cout[sc] = part;
-                cin = tcarry[sc];                    // open segment of the previous tile (rewritten after b1)
-            }
-            STAMP(3);
-            __syncthreads();                                                 // b1
-            STAMP(4);
-            if (k >= 0) {
-                // chain the two groups and the open segment of the previous tile, store the sums
-                if (sg == 1) { const float c0 = cout[sc]; cin = (mask & 0xFFFFu) ? c0 : cin + c0; }
-                bool open = true;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if ((gmask >> r) & 1u) {
-                        const int node = __builtin_amdgcn_readlane(ra, 16 * sg + r);
-                        a.aggr[(unsigned)(node * H + sc)] = open ? cin + xr[r] : xr[r];
-                        open = false;
-                    }
-                }
-                if (sg == 1) tcarry[sc] = gmask ? part : cin + part;         // read again after the next b1
-            }
-            STAMP(6);
-            if (i >= 1 && i <= ntiles) {             // tile i-1: second product + LayerNorm statistics
-                const int relm = (i - 1) * TM;
-#pragma unroll
-                for (int it = 0; it < 4; ++it)       // consumed one iteration later
-                    er[it] = *(const f32x4*)(ein_g + (unsigned)(min(relm + srow + 8 * it, last) * H + 4 * sq));
-                ra = rcv_g[min(relm + j, last)];
-                rb = (relm + j + 1 <= last) ? rcv_g[min(relm + j + 1, last)] : -1;
-                acc = acc_from_vec(vec[0], w, h);
-                acc = wave_gemm_h<0, 8, 8>(Hp[(i - 1) & 1], PLH, PKH, 0, wb, j, h, acc);
-                acc = relu16(acc);
-                ln_local_stats_rows(acc, red, w, j, h);
-            }
-            STAMP(5);
-            __syncthreads();                                                 // b2
-        }
-        STAMP_FLUSH(w == 0 ? 1 : -1)
-    }
-}
+constexpr int PLH = TM * PKH;         // halves per fp16 plane of a 32-row tile
 
 // ======================================================================== processor: edges, fp16 split, 4-wave workgroups
 // The edge update on the fp16 matrix pipe with the layout of mp_edge_kernel: two independent 4-wave
@@ -1427,14 +1235,8 @@ extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, 
     EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
                e_out, aggr, (int)n_edges, (int)n_nodes};
     if (matmul_mode() == 2) {
-        static const int eight = getenv("MGN_EDGE_8WAVE") ? 1 : 0;   // diagnostic: the role-split 8-wave variant
-        if (eight) {
-            const int g = grid_for((n_edges + TM - 1) / TM, 1);
-            hipLaunchKernelGGL(mp_edge_h_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);
-        } else {
-            const int g = grid_for((n_edges + TM - 1) / TM, 2);
-            hipLaunchKernelGGL(mp_edge_h4_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
-        }
+        const int g = grid_for((n_edges + TM - 1) / TM, 2);
+        hipLaunchKernelGGL(mp_edge_h4_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     } else if (matmul_mode() == 1) {
         const int g = grid_for((n_edges + TM - 1) / TM, 1);
         hipLaunchKernelGGL(mp_edge3_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);
