@@ -787,23 +787,26 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
     }
 }
 
-// out[(i / width) * ld + (i % width)] = sum over blocks of partial[b * stride + offset + i].  Eight
-// independent running sums per thread (blocks b = k mod 8) keep eight loads in flight; they are
-// combined pairwise in a fixed order, so the result does not depend on the launch.
-__global__ __launch_bounds__(64) void reduce_partials_kernel(const float* __restrict__ partial, int nblocks, int stride,
-                                                             int offset, int count, int width, int ld,
-                                                             float* __restrict__ out) {
+// Sums one workgroup-partial layout over the blocks, in block order: a matrix of `mcount` floats
+// (element i -> out[(i / H) * ld + (i % H)]; mcount may be 0) followed by `nvec` vectors of H floats
+// (vector v -> vec[v]).  Eight independent running sums per thread (blocks b = k mod 8) keep eight
+// loads in flight; they are combined pairwise in a fixed order, so the result does not depend on the launch.
+struct ReduceArgs { const float* partial; int nblocks; int stride; int mcount; int ld; float* out; int nvec; float* vec[3]; };
+
+__global__ __launch_bounds__(64) void reduce_partials_kernel(ReduceArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const float* p = partial + offset + i;
+    if (i >= a.mcount + a.nvec * H) return;
+    const float* p = a.partial + i;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int b = 0;
-    for (; b + 8 <= nblocks; b += 8) {
+    for (; b + 8 <= a.nblocks; b += 8) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += p[(size_t)(b + k) * stride];
+        for (int k = 0; k < 8; ++k) s[k] += p[(size_t)(b + k) * a.stride];
     }
-    for (int k = 0; b < nblocks; ++b, ++k) s[k] += p[(size_t)b * stride];
-    out[(size_t)(i / width) * ld + (i % width)] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    for (int k = 0; b < a.nblocks; ++b, ++k) s[k] += p[(size_t)b * a.stride];
+    const float sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    if (i < a.mcount) a.out[(size_t)(i / H) * a.ld + (i % H)] = sum;
+    else a.vec[(i - a.mcount) / H][(i - a.mcount) % H] = sum;
 }
 
 // ------------------------------------------------------------------------ segmented row sums
@@ -914,6 +917,12 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamEntry* __restrict__ 
     }
 }
 
+void launch_reduce(const float* partial, int nblocks, int stride, int mcount, int ld, float* out, int nvec, float* v0,
+                   float* v1, float* v2, hipStream_t s) {
+    ReduceArgs r{partial, nblocks, stride, mcount, ld, out, nvec, {v0, v1, v2}};
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((mcount + nvec * H + 63) / 64), dim3(64), 0, s, r);
+}
+
 int train_grid(long long rows, int per_cu) { return grid_for((rows + TM - 1) / TM, per_cu); }
 
 int stream_grid(long long items, int per_block) {
@@ -983,10 +992,7 @@ extern "C" int mgn_train_ln_bwd(const float* G, const float* Gg, const int32_t* 
     if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX;
     hipLaunchKernelGGL(train_ln_bwd_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, G, Gg, idx, v, gamma,
                        relu_mask, gpre, (float*)scratch, (long long)rows);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, (hipStream_t)stream, (const float*)scratch, g,
-                       2 * H, 0, H, H, H, dgamma);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, (hipStream_t)stream, (const float*)scratch, g,
-                       2 * H, H, H, H, H, dbeta);
+    launch_reduce((const float*)scratch, g, 2 * H, 0, 0, nullptr, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
     return check_launch("mgn_train_ln_bwd");
 }
 
@@ -1011,13 +1017,7 @@ extern "C" int mgn_train_linear_bwd(const float* G, const float* A, const float*
     } else if (GA && dW) hipLaunchKernelGGL((train_linear_bwd_kernel<true, true>), dim3(g), dim3(NT), 0, s, a);
     else if (GA) hipLaunchKernelGGL((train_linear_bwd_kernel<true, false>), dim3(g), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((train_linear_bwd_kernel<false, true>), dim3(g), dim3(NT), 0, s, a);
-    if (dW) {
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(PARTIAL_W / 64), dim3(64), 0, s, (const float*)scratch, g,
-                           PARTIAL, 0, PARTIAL_W, H, lddw, dW);
-        if (db)
-            hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, s, (const float*)scratch, g, PARTIAL,
-                               PARTIAL_W, H, H, H, db);
-    }
+    if (dW) launch_reduce((const float*)scratch, g, PARTIAL, PARTIAL_W, lddw, dW, db ? 1 : 0, db, nullptr, nullptr, s);
     return check_launch("mgn_train_linear_bwd");
 }
 
@@ -1036,12 +1036,7 @@ extern "C" int mgn_train_edge_bwd(const float* e_in, const float* g_e, const flo
                   (int)n_nodes, (int)n_edges};
     const int g = train_grid(n_edges, 1);
     hipLaunchKernelGGL(train_edge_bwd_kernel, dim3(g), dim3(NT), 0, s, a);
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(PARTIAL_W / 64), dim3(64), 0, s, (const float*)scratch, g, PARTIAL_E, 0,
-                       PARTIAL_W, H, H, dW1);
-    float* outs[3] = {db1, dgamma, dbeta};
-    for (int q = 0; q < 3; ++q)
-        hipLaunchKernelGGL(reduce_partials_kernel, dim3(H / 64), dim3(64), 0, s, (const float*)scratch, g, PARTIAL_E,
-                           PARTIAL_W + q * H, H, H, H, outs[q]);
+    launch_reduce((const float*)scratch, g, PARTIAL_E, PARTIAL_W, H, dW1, 3, db1, dgamma, dbeta, s);
     return check_launch("mgn_train_edge_bwd");
 }
 

@@ -57,8 +57,16 @@ class FusedAdam(torch.optim.Optimizer):
                                  st["exp_avg_sq"].data_ptr() + b, min(CHUNK, n - off)))
             if not rows:
                 continue
-            # freed after the launch: the caching allocator hands memory back only to later work on this stream
-            table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev, non_blocking=False)
+            # the table is uploaded again only when an address changed (gradients are usually re-allocated
+            # at the same addresses step after step)
+            cache = self.__dict__.setdefault("_tables", {})
+            key = (id(group), str(dev))
+            hit = cache.get(key)
+            if hit is not None and hit[0] == rows:
+                table = hit[1]
+            else:
+                table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev, non_blocking=False)
+                cache[key] = (rows, table)
             with torch.cuda.device(dev):
                 rc = _lib.lib().mgn_adam_step(C.c_void_p(table.data_ptr()), len(rows), float(group["lr"]),
                                               float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
