@@ -893,15 +893,28 @@ __global__ __launch_bounds__(NT, 2) void encode_kernel(EncArgs a) {
     const int ntiles = (a.rows + TM - 1) / TM;
     const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
     const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
+    // raw features of the next tile, requested one pass ahead (TM * FP <= 2 * NT elements)
+    constexpr int NPF = (TM * FP + NT - 1) / NT;
+    float pf[NPF];
+    auto request = [&](int tile) {
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int idx = t + q * NT, row = idx / FP, k = idx - row * FP;
+            const int n = min(tile * TM + row, a.rows - 1);
+            pf[q] = (idx < TM * FP && k < F) ? a.feat[(size_t)n * F + k] : 0.f;
+        }
+    };
+    if (t0 < t1) request(t0);
     __syncthreads();
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.rows - base);
-        for (int idx = t; idx < TM * FP; idx += NT) {
-            const int row = idx / FP, k = idx - row * FP;
-            const int n = min(base + row, a.rows - 1);
-            Fs[idx] = (k < F) ? (a.feat[(size_t)n * F + k] - ms[k]) / ms[MGN_MAX_FEAT + k] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int idx = t + q * NT, k = idx % FP;
+            if (idx < TM * FP) Fs[idx] = (k < F) ? (pf[q] - ms[k]) / ms[MGN_MAX_FEAT + k] : 0.f;
         }
         __syncthreads();
+        if (tile + 1 < t1) request(tile + 1);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it;
@@ -947,7 +960,7 @@ struct DecArgs {
 };
 
 template <bool HALF>
-__global__ __launch_bounds__(NT, 1) void decode_kernel(DecArgs a) {
+__global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short Xp[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];   // x tile: fp16 planes or fp32
     __shared__ __attribute__((aligned(16))) unsigned short Hq[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];   // hidden tile
     __shared__ __attribute__((aligned(16))) float vec[H];
@@ -981,17 +994,27 @@ __global__ __launch_bounds__(NT, 1) void decode_kernel(DecArgs a) {
     const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
     const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
     const int srow = t >> 5, sq = t & 31;
+    f32x4 pre[4];                                    // rows of the next tile, requested one pass ahead
+    if (t0 < t1) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+            pre[it] = *(const f32x4*)(a.x + (size_t)min(t0 * TM + srow + 8 * it, a.n_nodes - 1) * H + 4 * sq);
+    }
     __syncthreads();
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
-            const f32x4 v = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
-            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, v);
-            else *(f32x4*)(X + toff(row, sq, H / 4)) = v;
+            const int row = srow + 8 * it;
+            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, pre[it]);
+            else *(f32x4*)(X + toff(row, sq, H / 4)) = pre[it];
         }
         __syncthreads();
+        if (tile + 1 < t1) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                pre[it] = *(const f32x4*)(a.x + (size_t)min(base + TM + srow + 8 * it, a.n_nodes - 1) * H + 4 * sq);
+        }
         f32x16 acc = acc_from_vec(vec, w, h);
         if constexpr (HALF) {
             acc = wave_gemm_h<0, 8, 8>(Xp, PLH, PKH, 0, ha, j, h, acc);
@@ -1374,7 +1397,7 @@ extern "C" int mgn_decode(const float* x, const mgn_mlp* dec, int32_t time_dim, 
     MGN_REQUIRE(!pred || (out_dim == 3 && out_mean_std && world_pos && phi && node_type), "mgn_decode");
     DecArgs a{x, dec->w0, dec->b0, dec->w1, dec->b1, delta_norm, out_mean_std, world_pos, phi, node_type,
               pred, (int)n_nodes, (int)time_dim, (int)out_dim};
-    const int g = grid_for((n_nodes + TM - 1) / TM, 1);
+    const int g = grid_for((n_nodes + TM - 1) / TM, 2);
     if (matmul_mode() == 2) hipLaunchKernelGGL((decode_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((decode_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     return check_launch("mgn_decode");
