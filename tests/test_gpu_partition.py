@@ -103,14 +103,14 @@ def _thread_plan(ei, n, world, rank, bus):
     return ThreadPlan(ei, n, world, rank).to(DEV)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_rollout_matches_single_gpu(world):
+@pytest.mark.parametrize("world,nx,ny", [(2, 60, 45), (3, 60, 45), (4, 300, 260)])
+def test_partitioned_rollout_matches_single_gpu(world, nx, ny):
     from gnn_amd import partition
     from gnn_amd.graph import MeshGraph
     from test_gpu_model import build_model
     cfg = O.OracleConfig(process_steps=4)
     sd = O.init_state_dict(cfg, 3)
-    g = O.synthetic_graph(60, 45, seed=5)
+    g = O.synthetic_graph(nx, ny, seed=5)          # the largest case: 78k nodes, every launch spans many workgroups
     n = g["mesh_pos"].shape[0]
     steps = 3
 
