@@ -334,16 +334,26 @@ __device__ __forceinline__ f32x16 mfma32_bf16(u32x4 a, u32x4 b, f32x16 c) {
 template <int C0, int C1>
 __device__ __forceinline__ f32x16 wave_gemm3_32(const unsigned short* tile, const WPlanes32& w, int j, int h, f32x16 acc) {
     const unsigned short* r = tile + j * PK + 8 * h;
+    // the three LDS reads of a k-step are issued one step ahead of the six MFMAs that consume them
+    u32x4 xh = *(const u32x4*)(r + 16 * C0), xm = *(const u32x4*)(r + PLANE + 16 * C0),
+          xl = *(const u32x4*)(r + 2 * PLANE + 16 * C0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
     for (int c = C0; c < C1; ++c) {
-        const u32x4 xh = *(const u32x4*)(r + 16 * c), xm = *(const u32x4*)(r + PLANE + 16 * c),
-                    xl = *(const u32x4*)(r + 2 * PLANE + 16 * c);
+        u32x4 nh = xh, nm = xm, nl = xl;
+        if (c + 1 < C1) {
+            nh = *(const u32x4*)(r + 16 * (c + 1)); nm = *(const u32x4*)(r + PLANE + 16 * (c + 1));
+            nl = *(const u32x4*)(r + 2 * PLANE + 16 * (c + 1));
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+        }
         acc = mfma32_bf16(w.p[2][c], xh, acc);   // lo * hi
         acc = mfma32_bf16(w.p[0][c], xl, acc);   // hi * lo
         acc = mfma32_bf16(w.p[1][c], xm, acc);   // mid * mid
         acc = mfma32_bf16(w.p[1][c], xh, acc);   // mid * hi
         acc = mfma32_bf16(w.p[0][c], xm, acc);   // hi * mid
         acc = mfma32_bf16(w.p[0][c], xh, acc);   // hi * hi
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        xh = nh; xm = nm; xl = nl;
     }
     return acc;
 }

@@ -692,24 +692,27 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
             const int blk = 2 * s + h;
             const unsigned short* gp = G2T + tpos(32 * w + j, blk);
             const u32x4 gh = *(const u32x4*)gp, gm = *(const u32x4*)(gp + TPLANE), gl = *(const u32x4*)(gp + 2 * TPLANE);
-            u32x4 ah[4], am[4], al[4];
 #pragma unroll
-            for (int kb = 0; kb < 4; ++kb) {
-                const unsigned short* ap = H1T + tpos(32 * kb + j, blk);
-                ah[kb] = *(const u32x4*)ap; am[kb] = *(const u32x4*)(ap + TPLANE); al[kb] = *(const u32x4*)(ap + 2 * TPLANE);
+            for (int kp = 0; kp < 2; ++kp) {             // two column blocks at a time: 24 operand registers, not 48
+                u32x4 ah[2], am[2], al[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const unsigned short* ap = H1T + tpos(32 * (2 * kp + q) + j, blk);
+                    ah[q] = *(const u32x4*)ap; am[q] = *(const u32x4*)(ap + TPLANE); al[q] = *(const u32x4*)(ap + 2 * TPLANE);
+                }
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gl, ah[q], dw2[2 * kp + q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, al[q], dw2[2 * kp + q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gm, am[q], dw2[2 * kp + q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gm, ah[q], dw2[2 * kp + q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, am[q], dw2[2 * kp + q]);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, ah[q], dw2[2 * kp + q]);
             }
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gl, ah[kb], dw2[kb]);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gh, al[kb], dw2[kb]);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gm, am[kb], dw2[kb]);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gm, ah[kb], dw2[kb]);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gh, am[kb], dw2[kb]);
-#pragma unroll
-            for (int kb = 0; kb < 4; ++kb) dw2[kb] = mfma32_bf16(gh, ah[kb], dw2[kb]);
         }
         STAMP(11);
         acc = zero16();
