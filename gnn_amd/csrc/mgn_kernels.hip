@@ -750,8 +750,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         STAMP(10);
         if constexpr (PROJ) {
             f32x16 as = zero16(), ar = zero16();
-            as = wave_gemm_h<0, 8, 8>(Np, PL, PKH, 0, ws, j, h, as);
-            ar = wave_gemm_h<0, 8, 8>(Np, PL, PKH, 0, wr, j, h, ar);
+            wave_gemm_h2<0, 8, 8>(Np, PL, PKH, 0, ws, wr, j, h, as, ar);
 #pragma unroll
             for (int i = 0; i < 16; ++i) as[i] *= W_UNSCALE;
             ar = finish(ar, vec[4], false);
@@ -822,8 +821,7 @@ __global__ __launch_bounds__(NT, 2) void mp_project_kernel(ProjArgs a) {
         f32x16 as = zero16();
         f32x16 ar = acc_from_vec(vec, w, h);
         if constexpr (HALF) {
-            as = wave_gemm_h<0, 8, 8>(Xp, PLH, PKH, 0, hs, j, h, as);
-            ar = wave_gemm_h<0, 8, 8>(Xp, PLH, PKH, 0, hr, j, h, ar);
+            wave_gemm_h2<0, 8, 8>(Xp, PLH, PKH, 0, hs, hr, j, h, as, ar);
 #pragma unroll
             for (int i = 0; i < 16; ++i) { as[i] *= US; ar[i] *= US; }
         } else {
