@@ -47,25 +47,44 @@ class timed:
         return False
 
 
-def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def _stream() -> int:
+    """Raw handle of torch's current HIP stream."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
-def _dev(t: torch.Tensor, dtype, shape, name: str) -> C.c_void_p:
+def _bad_tensor(t, dtype, shape, name: str):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"{name}: expected a CUDA/HIP tensor (the HIP path has no CPU fallback)")
     if t.dtype != dtype:
         raise RuntimeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError(f"{name}: tensor must be contiguous")
-    if shape is not None:
-        if t.dim() != len(shape) or any(s is not None and int(d) != int(s) for d, s in zip(t.shape, shape)):
-            raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
-    return C.c_void_p(t.data_ptr())
+    raise RuntimeError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
 
 
-def _opt(t: Optional[torch.Tensor], dtype, shape, name: str) -> C.c_void_p:
-    return C.c_void_p(0) if t is None else _dev(t, dtype, shape, name)
+def _dev(t: torch.Tensor, dtype, shape, name: str) -> int:
+    """Device address of ``t`` after the host-side checks (this runs several times per launch: the
+    checks are ordered so that the passing case costs about a microsecond)."""
+    try:
+        ok = t.is_cuda and t.dtype is dtype and t.is_contiguous()
+    except AttributeError:
+        ok = False
+    if ok and shape is not None:
+        ts = t.shape
+        if len(ts) != len(shape):
+            ok = False
+        else:
+            for d, s in zip(ts, shape):
+                if s is not None and d != s:
+                    ok = False
+                    break
+    if not ok:
+        _bad_tensor(t, dtype, shape, name)
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], dtype, shape, name: str) -> int:
+    return 0 if t is None else _dev(t, dtype, shape, name)
 
 
 class MlpWeights:

@@ -176,8 +176,14 @@ def rollout_batched(model, trajectories, progress: bool = False):
     n_frames = len(trajectories[0])
     if any(len(tr) != n_frames for tr in trajectories):
         raise ValueError("rollout_batched: trajectories must have the same number of frames")
-    merged = [batch_graphs([tr[t] for tr in trajectories]) for t in range(n_frames)]
-    sizes = merged[0]["batch_sizes"]
+    # frame 0 carries the static fields of the union; of the later frames the rollout reads only the
+    # per-step fields, which are merged for all frames at once (one stack per trajectory and field)
+    merged0 = batch_graphs([tr[0] for tr in trajectories])
+    sizes = merged0["batch_sizes"]
+    series = {k: torch.cat([torch.stack([fr[k] for fr in tr]) for tr in trajectories], dim=1)
+              for k in ("world_pos", "phi", "swelling_phi")}
+    merged = [merged0] + [MeshGraph(time=trajectories[0][t]["time"], **{k: v[t] for k, v in series.items()})
+                          for t in range(1, n_frames)]
     res = rollout(model, merged, progress)
     preds, gts = unbatch_nodes(res["pred"], sizes, dim=1), unbatch_nodes(res["gt"], sizes, dim=1)
     swell = unbatch_nodes(res["swelling_phi"], sizes, dim=1)
