@@ -27,6 +27,10 @@ def set_event_log(log):
     _event_log = log
 
 
+def timing_enabled() -> bool:
+    return _event_log is not None
+
+
 class timed:
     __slots__ = ("name", "start")
 

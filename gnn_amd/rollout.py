@@ -13,21 +13,20 @@ import torch
 
 from .graph import MeshGraph, batch_graphs, unbatch_nodes
 
-GRAPH_MAX_NODES = 8192          # below this a step is bound by host launch overhead (measured: 561 nodes 0.73 -> 0.53 ms per step; at 36k nodes replay is slower than eager launches)
-
-
 def _wants_graph(model, first, use_graph):
+    """Graph replay is opt-in (``use_graph=True`` or ``MGN_ROLLOUT_GRAPH=1``): with the host-side cost
+    of a launch at a few microseconds, the eager sequence of a 561-node step (0.50 ms) is no slower
+    than replaying its captured graph (0.52 ms), and at 36k nodes replay is slower."""
     if use_graph is None:
-        env = os.environ.get("MGN_ROLLOUT_GRAPH", "")
-        use_graph = first["mesh_pos"].shape[0] <= GRAPH_MAX_NODES if env == "" else env != "0"
+        use_graph = os.environ.get("MGN_ROLLOUT_GRAPH", "0") not in ("", "0")
     return bool(use_graph) and model.__dict__.get("halo") is None and torch.device(model.device).type == "cuda"
 
 
 class _StepGraph:
     """One rollout step -- ``predict`` plus the state feedback -- captured as a HIP graph.
 
-    The step's ~45 launches cost more host time than GPU time on a small mesh; replaying the
-    captured sequence is one launch.  What changes from step to step lives in fixed device
+    Replaying the captured sequence is one launch instead of ~45; it pays where the host is the
+    bottleneck (slow host cores, many small meshes driven from one thread).  What changes from step to step lives in fixed device
     buffers: the state (fed back inside the graph), the swelling window (copied in before each
     replay) and the normalisers' row counts (``Normalizer.use_device_count``)."""
 
@@ -90,8 +89,8 @@ class _StepGraph:
 def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
     """``reorder``: None, or "rcm" / "morton" to renumber the nodes for locality before the
     first step (meshes whose ids do not follow the geometry); every returned tensor stays in
-    the order of ``data``.  ``use_graph``: replay each step as one captured HIP graph (default:
-    meshes up to ``GRAPH_MAX_NODES`` nodes; ``MGN_ROLLOUT_GRAPH=0/1`` overrides the default)."""
+    the order of ``data``.  ``use_graph``: replay each step as one captured HIP graph (default off;
+    ``MGN_ROLLOUT_GRAPH=1`` turns it on)."""
     if reorder is not None:
         return _rollout_reordered(model, data, progress, reorder, use_graph)
     device = model.device
