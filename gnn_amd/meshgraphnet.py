@@ -325,6 +325,16 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         return self.output_normalizer((target[:, :n] - cur[:n]).contiguous(),
                                       partial_sums_hook=halo.sum_hook("node")).contiguous()
 
+    def _param_list(self):
+        """(names, parameters) in ``named_parameters`` order, listed once: walking the module tree
+        costs more host time than a small mesh's whole forward pass."""
+        cached = self.__dict__.get("_mgn_params")
+        if cached is None:
+            named = list(self.named_parameters())
+            cached = ([k for k, _ in named], [p for _, p in named])
+            self.__dict__["_mgn_params"] = cached
+        return cached
+
     def loss(self, graph):
         """Masked squared error between the normalised target delta and the prediction
         (core/meshgraphnet.py:285-304): returns (total, ux, uy, phi).  The output normaliser
@@ -333,7 +343,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         as run_train_multiscale.py:139-141 expects."""
         from . import training
         tgt = self._normalized_target(graph)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()[1]):
             comps = training.loss_components(self, graph, tgt)
         else:
             comps, _ = training.forward_saving(self, graph, tgt)
@@ -368,4 +378,5 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             if nrm._acc_sum.device != dev:
                 nrm.to_device(dev)
         self.__dict__["_ws"] = None
+        self.__dict__["_mgn_params"] = None
         return self

@@ -29,46 +29,47 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
-            rows, dev, step = [], None, None
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                    raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU")
-                g = p.grad
-                if g.is_sparse or g.dtype != torch.float32 or g.device != p.device:
-                    raise RuntimeError("FusedAdam: gradients must be dense fp32 tensors on the parameter's device")
-                g = g if g.is_contiguous() else g.contiguous()
+        for gi, group in enumerate(self.param_groups):
+            params = [p for p in group["params"] if p.grad is not None]
+            if not params:
+                continue
+            dev = params[0].device
+            for p in params:
                 st = self.state[p]
                 if not st:
+                    if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                        raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU")
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 st["step"] += 1
-                if step is None:
-                    step, dev = st["step"], p.device
-                elif st["step"] != step or p.device != dev:
-                    raise RuntimeError("FusedAdam: all parameters of a group must share step count and device")
-                n = p.numel()
-                for off in range(0, n, CHUNK):
-                    b = 4 * off
-                    rows.append((p.data_ptr() + b, g.data_ptr() + b, st["exp_avg"].data_ptr() + b,
-                                 st["exp_avg_sq"].data_ptr() + b, min(CHUNK, n - off)))
-            if not rows:
-                continue
-            # the table is uploaded again only when an address changed (gradients are usually re-allocated
-            # at the same addresses step after step)
+            step = self.state[params[0]]["step"]
+            # the pointer table is rebuilt and uploaded only when an address changed (gradients are
+            # usually re-allocated at the same addresses step after step)
+            key = tuple(p.grad.data_ptr() for p in params) + tuple(p.data_ptr() for p in params)
             cache = self.__dict__.setdefault("_tables", {})
-            key = (id(group), str(dev))
-            hit = cache.get(key)
-            if hit is not None and hit[0] == rows:
-                table = hit[1]
-            else:
+            hit = cache.get(gi)
+            if hit is None or hit[0] != key:
+                rows, keep = [], []
+                for p in params:
+                    g, st = p.grad, self.state[p]
+                    if g.is_sparse or g.dtype != torch.float32 or g.device != p.device or p.device != dev:
+                        raise RuntimeError("FusedAdam: gradients must be dense fp32 tensors on the parameters' device")
+                    if st["step"] != step:
+                        raise RuntimeError("FusedAdam: all parameters of a group must share their step count")
+                    if not g.is_contiguous():
+                        g = g.contiguous()
+                        keep.append(g)
+                    n = p.numel()
+                    for off in range(0, n, CHUNK):
+                        b = 4 * off
+                        rows.append((p.data_ptr() + b, g.data_ptr() + b, st["exp_avg"].data_ptr() + b,
+                                     st["exp_avg_sq"].data_ptr() + b, min(CHUNK, n - off)))
                 table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev, non_blocking=False)
-                cache[key] = (rows, table)
+                hit = (key if not keep else None, table, len(rows), keep)      # copies of strided gradients are not reusable
+                cache[gi] = hit
             with torch.cuda.device(dev):
-                rc = _lib.lib().mgn_adam_step(C.c_void_p(table.data_ptr()), len(rows), float(group["lr"]),
+                rc = _lib.lib().mgn_adam_step(C.c_void_p(hit[1].data_ptr()), hit[2], float(group["lr"]),
                                               float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
                                               float(group["weight_decay"]), int(step),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))

@@ -292,7 +292,7 @@ class _LossFn(torch.autograd.Function):
     def forward(ctx, model, graph, target_norm, *params):
         loss3, saved = forward_saving(model, graph, target_norm)
         ctx.model, ctx.saved_acts = model, saved
-        ctx.names = [k for k, _ in model.named_parameters()]
+        ctx.names = model._param_list()[0]
         return loss3
 
     @staticmethod
@@ -304,5 +304,4 @@ class _LossFn(torch.autograd.Function):
 
 def loss_components(model, graph, target_norm):
     """[3] tensor (ux, uy, phi) attached to the autograd graph of the model's parameters."""
-    params = [p for _, p in model.named_parameters()]
-    return _LossFn.apply(model, graph, target_norm, *params)
+    return _LossFn.apply(model, graph, target_norm, *model._param_list()[1])

@@ -26,3 +26,27 @@ for _ in range(200):
 torch.cuda.synchronize()
 pr.disable()
 pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+
+# ---- the same for a training step
+from gnn_amd.optim import FusedAdam  # noqa: E402
+g["target"] = torch.cat([g["world_pos"], g["phi"]], -1).unsqueeze(0) + 1e-4 * torch.randn(1, g["mesh_pos"].shape[0], 3, device=dev)
+m.train()
+opt = FusedAdam(m.parameters(), lr=1e-4)
+
+
+def train_step():
+    opt.zero_grad()
+    m.loss(g)[0].backward()
+    opt.step()
+
+
+for _ in range(10):
+    train_step()
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(50):
+    train_step()
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)
