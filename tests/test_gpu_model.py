@@ -363,3 +363,31 @@ def frames_to_window(frames, t, time_dim):
     sw = [frames[min(t + k, len(frames) - 1)]["swelling_phi"] for k in range(time_dim + 1)]
     g["swelling_phi"] = torch.stack(sw, dim=1)
     return g.to(DEV)
+
+
+@pytest.mark.parametrize("time_dim,n_frames", [(2, 11), (3, 10)])
+def test_rollout_multi_step_windows_vs_oracle(time_dim, n_frames):
+    """Rollout with several predicted frames per step (time_dim > 1): swelling windows that run past
+    the end of the trajectory are zero padded, the output is cut to the trajectory length and the
+    last predicted frame is fed back (core/rollout.py:17-36) -- against the oracle's rollout with
+    fresh, accumulating statistics on both sides (2e-5 as in test_predict_general_config_golden)."""
+    import gnn_amd
+    from gnn_amd.rollout import rollout
+    cfg = O.OracleConfig(process_steps=2, time_dim=time_dim, node_in_dim=9 + time_dim)
+    sd = O.init_state_dict(cfg, 21)
+    frames = gnn_amd.synthetic_frames(11, 7, n_frames=n_frames, seed=4)
+    model = build_model(cfg, sd)
+    res = rollout(model, frames)
+    static = {k: frames[0][k] for k in ("mesh_pos", "node_type", "mat_param", "edge_index")}
+    world = torch.stack([fr["world_pos"] for fr in frames])
+    phi = torch.stack([fr["phi"] for fr in frames])
+    swell = torch.stack([fr["swelling_phi"] for fr in frames])
+    norms = O.make_norms(cfg)
+    with torch.no_grad():
+        ref, rmse = O.rollout(sd, cfg, norms, static, world, phi, swell)
+    assert res["pred"].shape == ref.shape == (n_frames, world.shape[1], 3)
+    assert rel_l2(res["pred"], ref) < 2e-5, rel_l2(res["pred"], ref)
+    got = torch.stack([res["rmse_x"], res["rmse_y"], res["rmse_phi"]]).cpu()
+    assert torch.allclose(got, rmse, rtol=1e-3)
+    assert model.node_features_normalizer._num_accumulations == norms["node"].num_accumulations
+    assert model.node_features_normalizer._acc_count == norms["node"].acc_count
