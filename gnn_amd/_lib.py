@@ -28,6 +28,10 @@ SIGNATURES = {
     "mgn_last_error": (C.c_char_p, []),
     "mgn_cells_to_edge_index": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _P]),
     "mgn_receiver_csr": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "mgn_edge_build_workspace_bytes": (C.c_int64, [_I64]),
+    "mgn_cells_to_edge_index_dev": (C.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _P]),
+    "mgn_receiver_csr_workspace_bytes": (C.c_int64, [_I64]),
+    "mgn_receiver_csr_dev": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "mgn_mp_project": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P]),
     "mgn_mp_edge": (C.c_int, [_P, _P, _P, _P, _P, _P, _MLP, _P, _P, _I64, _I64, _P]),
     "mgn_mp_node": (C.c_int, [_P, _P, _P, _MLP, _P, _I64, _P]),

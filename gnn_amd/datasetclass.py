@@ -21,6 +21,8 @@ from .graph import MeshGraph
 def cells_to_edge_index(cells: torch.Tensor) -> torch.Tensor:
     """Triangular cells [C,3] -> directed, duplicate-free edge_index [2,E] (int64), sorted by
     (sender, receiver), both directions of every triangle side present."""
+    if torch.is_tensor(cells) and cells.is_cuda:          # mesh already in HBM: build the edges there
+        return ops.cells_to_edge_index_dev(cells.detach())[0]
     arr = cells.detach().cpu().numpy() if torch.is_tensor(cells) else np.asarray(cells)
     ei, _ = ops.cells_to_edge_index_np(arr)
     return torch.from_numpy(ei)

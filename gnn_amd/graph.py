@@ -114,18 +114,29 @@ class Topology:
     rowptr[n] .. rowptr[n+1]-1; ``perm[j]`` is the position of CSR edge j in ``edge_index``."""
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, device):
-        ei = edge_index.detach().to("cpu", torch.int64).numpy()
-        if ei.ndim != 2 or ei.shape[0] != 2:
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise RuntimeError(f"edge_index must have shape [2, E], got {tuple(edge_index.shape)}")
-        rowptr, cs, cr, perm = ops.receiver_csr_np(ei, int(num_nodes))   # range-checks every id
-        self.num_nodes, self.num_edges = int(num_nodes), int(ei.shape[1])
+        self.num_nodes, self.num_edges = int(num_nodes), int(edge_index.shape[1])
         self.device = torch.device(device)
-        self.rowptr = torch.from_numpy(rowptr).to(self.device)
-        self.sender = torch.from_numpy(np.ascontiguousarray(cs)).to(self.device)
-        self.recv = torch.from_numpy(np.ascontiguousarray(cr)).to(self.device)
-        self.perm = torch.from_numpy(np.ascontiguousarray(perm)).to(self.device)
-        self.max_in_degree = int(np.diff(rowptr).max()) if num_nodes > 0 else 0
+        if edge_index.is_cuda and edge_index.device == self._resolved(self.device):
+            # the edge list is already in HBM: sort it there (range-checks every id)
+            self.rowptr, self.sender, self.recv, self.perm = ops.receiver_csr_dev(edge_index.detach(), int(num_nodes))
+            self.max_in_degree = int((self.rowptr[1:] - self.rowptr[:-1]).max()) if num_nodes > 0 and self.num_edges else 0
+        else:
+            ei = edge_index.detach().to("cpu", torch.int64).numpy()
+            rowptr, cs, cr, perm = ops.receiver_csr_np(ei, int(num_nodes))   # range-checks every id
+            self.rowptr = torch.from_numpy(rowptr).to(self.device)
+            self.sender = torch.from_numpy(np.ascontiguousarray(cs)).to(self.device)
+            self.recv = torch.from_numpy(np.ascontiguousarray(cr)).to(self.device)
+            self.perm = torch.from_numpy(np.ascontiguousarray(perm)).to(self.device)
+            self.max_in_degree = int(np.diff(rowptr).max()) if num_nodes > 0 else 0
         self._sender_view = None
+
+    @staticmethod
+    def _resolved(device: torch.device) -> torch.device:
+        if device.type == "cuda" and device.index is None:
+            return torch.device("cuda", torch.cuda.current_device())
+        return device
 
     def sender_view(self):
         """(sender_rowptr int32 [N+1], sender_order int32 [E]): the CSR edges sent by node n are

@@ -144,6 +144,52 @@ def receiver_csr_np(edge_index: np.ndarray, num_nodes: int):
     return rowptr, cs[:ne], cr[:ne], perm[:ne]
 
 
+# --------------------------------------------------------------------------- device: edge build
+def cells_to_edge_index_dev(cells: torch.Tensor) -> Tuple[torch.Tensor, int]:
+    """Device version of :func:`cells_to_edge_index_np` for a CUDA ``cells`` tensor: returns
+    (edge_index int64 [2, E] on the same device, number of nodes = max id + 1)."""
+    cells = cells.reshape(-1, 3).to(torch.int64).contiguous()
+    nc = cells.shape[0]
+    dev = cells.device
+    if nc == 0:
+        return torch.empty(2, 0, dtype=torch.int64, device=dev), 0
+    with torch.cuda.device(dev):
+        need = int(_lib.lib().mgn_edge_build_workspace_bytes(nc))
+        if need < 0:
+            raise RuntimeError("cells_to_edge_index: too many cells for the device build (6 * cells must stay below 2^31)")
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty(2, 6 * nc, dtype=torch.int64, device=dev)
+        ne, nn = C.c_int64(0), C.c_int64(0)
+        rc = _lib.lib().mgn_cells_to_edge_index_dev(_dev(cells, torch.int64, (nc, 3), "cells"), nc, ws.data_ptr(), need,
+                                                    out[0].data_ptr(), out[1].data_ptr(), 6 * nc, C.addressof(ne),
+                                                    C.addressof(nn), _stream())
+        _lib.check(rc, "mgn_cells_to_edge_index_dev")
+    return out[:, : ne.value].contiguous(), int(nn.value)
+
+
+def receiver_csr_dev(edge_index: torch.Tensor, num_nodes: int):
+    """Device version of :func:`receiver_csr_np` for a CUDA ``edge_index``: (rowptr int32 [N+1],
+    csr_sender int32 [E], csr_recv int32 [E], perm int64 [E]) on the same device."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise RuntimeError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+    ei = edge_index.to(torch.int64).contiguous()
+    ne, dev = ei.shape[1], ei.device
+    rowptr = torch.empty(num_nodes + 1, dtype=torch.int32, device=dev)
+    cs = torch.empty(ne, dtype=torch.int32, device=dev)
+    cr = torch.empty(ne, dtype=torch.int32, device=dev)
+    perm = torch.empty(ne, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        need = int(_lib.lib().mgn_receiver_csr_workspace_bytes(ne))
+        if need < 0:
+            raise RuntimeError("receiver_csr: sizes exceed the int32 index range")
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        rc = _lib.lib().mgn_receiver_csr_dev(ei[0].data_ptr(), ei[1].data_ptr(), ne, int(num_nodes), ws.data_ptr(), need,
+                                             _dev(rowptr, torch.int32, (num_nodes + 1,), "rowptr"), cs.data_ptr(),
+                                             cr.data_ptr(), perm.data_ptr(), _stream())
+        _lib.check(rc, "mgn_receiver_csr_dev")
+    return rowptr, cs, cr, perm
+
+
 # --------------------------------------------------------------------------- device: processor
 def mp_project(x, w0, b0, ps, pr):
     n = x.shape[0]

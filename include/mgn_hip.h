@@ -68,6 +68,22 @@ int mgn_receiver_csr(const int64_t* sender, const int64_t* recv, int64_t n_edges
                      int32_t* rowptr /*[N+1]*/, int32_t* csr_sender /*[E]*/, int32_t* csr_recv /*[E]*/,
                      int64_t* perm /*[E]*/);
 
+/* ---- the same two builds for meshes that already live in device memory -------------------------
+ * Same results, integer for integer, as mgn_cells_to_edge_index / mgn_receiver_csr; all array
+ * arguments are device pointers, the two size outputs of the first are host pointers.  `workspace`
+ * is caller-provided device memory of at least mgn_*_workspace_bytes() bytes.  Because sizes travel
+ * back to the host (node count, edge count, range check) these calls synchronise `stream`; they run
+ * once per mesh.  Key generation, splitting and the CSR scatter are kernels of the library, the key
+ * sorts and the duplicate removal are hipCUB device primitives.                                    */
+int64_t mgn_edge_build_workspace_bytes(int64_t n_cells);
+int mgn_cells_to_edge_index_dev(const int64_t* cells, int64_t n_cells, void* workspace, int64_t ws_bytes,
+                                int64_t* out_sender, int64_t* out_recv, int64_t cap, int64_t* out_n_edges /*host*/,
+                                int64_t* out_n_nodes /*host*/, void* stream);
+int64_t mgn_receiver_csr_workspace_bytes(int64_t n_edges);
+int mgn_receiver_csr_dev(const int64_t* sender, const int64_t* recv, int64_t n_edges, int64_t n_nodes, void* workspace,
+                         int64_t ws_bytes, int32_t* rowptr, int32_t* csr_sender, int32_t* csr_recv, int64_t* perm,
+                         void* stream);
+
 /* ---- device side: processor (core/meshgraphnet.py:86-120, attention off) ----------
  * The first edge Linear acts on cat[x[s], x[r], e] (:95); it is evaluated as
  *   ps[s] + pr[r] + e @ W0[:, 2H:3H]^T,  ps = x @ W0[:, 0:H]^T,  pr = x @ W0[:, H:2H]^T + b0
