@@ -143,12 +143,18 @@ class Topology:
         ``sender_order[sender_rowptr[n] : sender_rowptr[n+1]]`` in ascending CSR position.  Used
         by the backward pass to sum edge gradients per sender without atomics."""
         if self._sender_view is None:
-            snd = self.sender.cpu().numpy()
-            order = np.argsort(snd, kind="stable").astype(np.int32)
-            rowptr = np.zeros(self.num_nodes + 1, dtype=np.int64)
-            np.cumsum(np.bincount(snd, minlength=self.num_nodes), out=rowptr[1:])
-            self._sender_view = (torch.from_numpy(rowptr.astype(np.int32)).to(self.device),
-                                 torch.from_numpy(order).to(self.device))
+            if self.sender.is_cuda:
+                # the same stable device sort with the roles swapped: "receivers" = the CSR senders
+                swapped = torch.stack([self.recv, self.sender]).to(torch.int64)
+                rowptr, _, _, perm = ops.receiver_csr_dev(swapped, self.num_nodes)
+                self._sender_view = (rowptr, perm.to(torch.int32))
+            else:
+                snd = self.sender.cpu().numpy()
+                order = np.argsort(snd, kind="stable").astype(np.int32)
+                rowptr = np.zeros(self.num_nodes + 1, dtype=np.int64)
+                np.cumsum(np.bincount(snd, minlength=self.num_nodes), out=rowptr[1:])
+                self._sender_view = (torch.from_numpy(rowptr.astype(np.int32)).to(self.device),
+                                     torch.from_numpy(order).to(self.device))
         return self._sender_view
 
 
