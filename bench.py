@@ -117,11 +117,18 @@ def main():
             raise SystemExit("bench.py --gpus N (N > 1) must be launched with torch.distributed.run, one rank per GPU")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # MGN_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks
+    # share devices, halos travel through host memory); the default is RCCL, one GPU per rank
+    backend = os.environ.get("MGN_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world_size > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from gnn_amd import ops
     model, g_full, g, plan, n, e = build_problem(args.grid, args.mp_steps, device, world_size, rank)
@@ -150,7 +157,7 @@ def main():
     ops.set_event_log(None)
     if world_size > 1:
         import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     finite = bool(torch.isfinite(g["world_pos"]).all())

@@ -124,6 +124,8 @@ class HaloPlan:
             return None if async_op else buf
         send = buf.index_select(0, self.send_idx) if self.send_idx.numel() else buf.new_empty((0, buf.shape[1]))
         recv = buf[self.num_owned:]
+        if self._host_staged(buf):
+            return self._staged_all_to_all(recv, send, self.recv_counts, self.send_counts, async_op, buf)
         work = dist.all_to_all_single(recv, send, output_split_sizes=self.recv_counts, input_split_sizes=self.send_counts,
                                       group=self.group, async_op=async_op)
         return work if async_op else buf
@@ -138,8 +140,11 @@ class HaloPlan:
             return None if async_op else buf
         send = buf[self.num_owned:].contiguous()
         recv = buf.new_empty((int(self.send_idx.numel()), buf.shape[1]))
-        work = dist.all_to_all_single(recv, send, output_split_sizes=self.send_counts, input_split_sizes=self.recv_counts,
-                                      group=self.group, async_op=async_op)
+        if self._host_staged(buf):
+            work = self._staged_all_to_all(recv, send, self.send_counts, self.recv_counts, True, None)
+        else:
+            work = dist.all_to_all_single(recv, send, output_split_sizes=self.send_counts,
+                                          input_split_sizes=self.recv_counts, group=self.group, async_op=async_op)
         plan = self
 
         class _Pending:
@@ -165,8 +170,33 @@ class HaloPlan:
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         """Sum over the ranks of the plan's group, in place."""
         if self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            if self._host_staged(t):
+                c = t.cpu()
+                dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group)
+                t.copy_(c)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
+
+    # A process group without a device transport (gloo) moves device tensors through host memory.  This is
+    # for rehearsing the multi-rank path on a machine without RCCL peers (several ranks on one GPU); the
+    # arithmetic still runs in the HIP kernels.
+    def _host_staged(self, t: torch.Tensor) -> bool:
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _staged_all_to_all(self, recv, send, out_splits, in_splits, async_op, ret):
+        recv_c = torch.empty(recv.shape, dtype=recv.dtype)
+        dist.all_to_all_single(recv_c, send.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
+                               group=self.group)
+
+        class _Done:
+            def wait(self_inner):
+                recv.copy_(recv_c)
+
+        if async_op:
+            return _Done()
+        recv.copy_(recv_c)
+        return ret
 
     def exchange_state(self, world_pos: torch.Tensor, phi: torch.Tensor):
         """Refreshes the halo rows of the per-step state (3 floats per halo node)."""
@@ -182,8 +212,7 @@ class HaloPlan:
         total = self.global_nodes if kind == "node" else self.global_edges
 
         def hook(sums: torch.Tensor) -> int:
-            if self.world_size > 1:
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+            self.all_reduce_(sums)
             return total
         return hook
 
