@@ -4,6 +4,9 @@ square mesh: the 250k-node / 10 message-passing-step training configuration by d
 
     python scripts/bench_train.py [--grid 500] [--mp-steps 10] [--steps 5] [--warmup 2] [--cpu-grid 100]
 
+Under ``python -m torch.distributed.run --nproc-per-node N`` the mesh is grid x (N * grid) nodes cut into
+N strips (one rank each, RCCL; MGN_DIST_BACKEND=gloo rehearses it with ranks sharing GPUs).
+
 Prints one JSON line.  The CPU figure is the oracle's autograd (torch CPU, all host threads) on a
 smaller mesh, scaled by edge count."""
 import argparse
@@ -30,16 +33,34 @@ def main():
     import gnn_amd
     from gnn_amd import ops
     from gnn_amd.meshgraphnet import EncodeProcessDecodeMultiScale
-    dev = torch.device("cuda", 0)
-    g = gnn_amd.synthetic_frames(args.grid - 1, args.grid - 1, n_frames=1, seed=0)[0]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MGN_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        import torch.distributed as dist
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    g = gnn_amd.synthetic_frames(args.grid - 1, args.grid * world - 1, n_frames=1, seed=0)[0]
     n, e = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
     gen = torch.Generator().manual_seed(1)
     g["target"] = torch.cat([g["world_pos"], g["phi"]], -1).unsqueeze(0) + 1e-3 * torch.randn(1, n, 3, generator=gen)
+    plan = None
+    if world > 1:
+        from gnn_amd import partition
+        plan = partition.HaloPlan(g["edge_index"].numpy(), n, world, rank).to(dev)
+        g = plan.local_graph(g)
     g = g.to(dev)
     torch.manual_seed(0)
     model = EncodeProcessDecodeMultiScale(10, 7, hidden_size=128, process_steps=args.mp_steps, coarse_process_steps=0,
                                           node_out_dim=3, attention=False, with_mat_params=False, sample_ratio=0.0,
                                           time_dim=1, device=dev).to(dev).train()
+    if plan is not None:
+        partition.attach(model, plan)
     from gnn_amd.optim import FusedAdam
     opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-5)
 
@@ -76,7 +97,16 @@ def main():
                       "nodes": n, "edges": e, "mp_steps": args.mp_steps},
            "edge_updates_fwd_bwd_per_s": e * args.mp_steps / dt, "dtype": "f32", "loss": float(last.detach()),
            "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9}
-    if args.cpu_grid > 0:
+    if world > 1:
+        out["n_gpus"], out["config"]["parallelism"] = world, f"node-range partition x{world}, {args.grid}x{args.grid} nodes per rank"
+        gsum = torch.stack([p.grad.double().abs().sum() for p in model.parameters()]).sum().reshape(1).cpu()
+        both = [torch.zeros_like(gsum) for _ in range(world)]
+        dist.all_gather(both, gsum)
+        out["grad_checksum_equal_on_all_ranks"] = bool(all(torch.equal(b, both[0]) for b in both))
+        if rank != 0:
+            dist.destroy_process_group()
+            return
+    if args.cpu_grid > 0 and world == 1:
         import oracle as O
         torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))))
         cfg = O.OracleConfig(process_steps=args.mp_steps)
@@ -95,6 +125,8 @@ def main():
                                f"{tc * 1e3:.0f} ms per step", "edge_updates_fwd_bwd_per_s": ec * args.mp_steps / tc,
                                "steps_per_s_scaled_to_workload": 1.0 / (tc * e / ec)}
     print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
