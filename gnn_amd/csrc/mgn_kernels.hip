@@ -142,7 +142,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     const int idx = tt + 128 * (4 * half + it), row = idx >> 5, q = idx & 31;
-                    if (row < nvalid) *(f32x4*)(a.e_out + (size_t)(base + row) * H + 4 * q) = y[it] + x[it];
+                    if (row < nvalid && a.e_out) *(f32x4*)(a.e_out + (size_t)(base + row) * H + 4 * q) = y[it] + x[it];
                 }
             }
         } else {
@@ -321,7 +321,7 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
                 for (int it = 0; it < 4; ++it) {     // residual + coalesced store
                     const int row = srow + 8 * it;
                     const f32x4 y = *(const f32x4*)(Es + toff(row, sq, H / 4));
-                    if (row < nvalid) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y + er[it];
+                    if (row < nvalid && a.e_out) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y + er[it];
                 }
                 // receiver-segmented sum: thread (column sc, group sg) scans rows 16sg .. 16sg+15 in
                 // order; xr[r] = sum of the rows since the last segment end before r
@@ -505,7 +505,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = srow + 8 * it;
-                if (row < nvalid) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y[it];
+                if (row < nvalid && a.e_out) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y[it];
             }
         }
         bool open = true;
@@ -1250,7 +1250,7 @@ extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, 
                            float* aggr, int64_t n_edges, int64_t n_nodes, void* stream) {
     MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31) && n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_mp_edge");
     if (n_edges == 0) return 0;
-    MGN_REQUIRE(e_in && ps && pr && rowptr && csr_sender && csr_recv && e_out && aggr && mlp_ok(m, true), "mgn_mp_edge");
+    MGN_REQUIRE(e_in && ps && pr && rowptr && csr_sender && csr_recv && aggr && mlp_ok(m, true), "mgn_mp_edge");
     // node rows are addressed with 32-bit element offsets
     MGN_REQUIRE(n_nodes * (int64_t)H < (1ll << 31), "mgn_mp_edge");
     EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,

@@ -122,20 +122,23 @@ class EdgeNodeMessagePassing(nn.Module):
                                   nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.LayerNorm(hidden_dim))
         self.__dict__["_topo"] = TopologyCache()
 
-    def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr, halo=None, projected=False, next_block=None):
+    def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr, halo=None, projected=False, next_block=None,
+                 store_edges=True):
         """In place on ``x`` [N,H] and ``e_csr`` [E,H] (receiver-major edge order).
 
         ``projected``: ``ps``/``pr`` already hold this block's per-node projections (written by
         the previous block's fused node kernel).  ``next_block``: the block that runs next; its
-        projections are then produced by this block's node kernel.  With a ``halo`` plan only
+        projections are then produced by this block's node kernel.  ``store_edges=False``: the
+        updated edge latents are not written (last block of a stack).  With a ``halo`` plan only
         the first ``halo.num_owned`` rows of ``x`` are owned; the sender projections of the
         remaining (halo) rows arrive from their owners."""
         ew, nw = self.edge_mlp.weights(), self.node_mlp.weights()
         n = x.shape[0] if halo is None else halo.num_owned
+        e_out = e_csr if store_edges else None
         if halo is None and not ops.timing_enabled():       # the common path, without the timing contexts
             if not projected:
                 ops.mp_project(x, self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps, pr)
-            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
+            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr)
             if next_block is None:
                 ops.mp_node(x, aggr, topo.rowptr, nw, x)
             else:
@@ -147,19 +150,19 @@ class EdgeNodeMessagePassing(nn.Module):
                 ops.mp_project(x[:n], self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps[:n], pr[:n])
         if halo is None:
             with ops.timed("mp_edge"):
-                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr)
+                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr)
         else:
             # the receivers whose in-edges all come from owned senders are updated while the halo
             # rows of `ps` are in flight; the rest follows once they have arrived
             with ops.timed("halo_exchange"):
                 pending = halo.exchange_rows(ps, async_op=True)
             with ops.timed("mp_edge"):
-                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr, node_range=halo.interior)
+                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=halo.interior)
             if pending is not None:
                 pending.wait()
             with ops.timed("mp_edge_boundary"):
                 for rng in halo.boundary:
-                    ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_csr, aggr, node_range=rng)
+                    ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=rng)
         with ops.timed("mp_node"):
             if next_block is None:
                 ops.mp_node(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, x[:n])
@@ -283,8 +286,9 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         ops.encode(ws.edge_feat, ms_e, self.edge_encoder.weights(), ws.e)
         blocks = list(self.processors)
         for i, proc in enumerate(blocks):
+            last = i + 1 == len(blocks)           # nothing reads the edge latents after the last block
             proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr, halo, projected=i > 0,
-                          next_block=blocks[i + 1] if i + 1 < len(blocks) else None)
+                          next_block=None if last else blocks[i + 1], store_edges=not last)
         return ws, topo
 
     # ----------------------------------------------------------------- reference API

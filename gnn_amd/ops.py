@@ -223,7 +223,7 @@ def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, 
                                 _dev(pr, torch.float32, (n, H), "pr"), rp,
                                 _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
                                 _dev(csr_recv, torch.int32, (ne,), "csr_recv"), mlp.ref(),
-                                _dev(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (None, H), "aggr"),
+                                _opt(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (None, H), "aggr"),
                                 e_sub, n_sub, _stream())
     _lib.check(rc, "mgn_mp_edge")
 

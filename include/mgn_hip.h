@@ -95,7 +95,8 @@ int mgn_mp_project(const float* x /*[N][H]*/, const float* edge_w0 /*[H][3H]*/, 
  * e_out = LN(ReLU(W1 ReLU(first Linear) + b1)) + e_in ; aggr[n] = sum of the
  * pre-residual outputs over the in-edges of n, added in CSR order (deterministic).
  * Rows of aggr belonging to nodes without in-edges are left untouched.
- * e_out may alias e_in.
+ * e_out may alias e_in, and may be NULL: the updated edge latents are then not stored (the last
+ * block of a stack, whose edge output nothing reads; saves the 512 B/edge write).
  * Receiver sub-range: rowptr may point at entry n0 of a larger CSR (rowptr[0] need not be 0);
  * n_nodes / n_edges then count the receivers n0 .. n0+n_nodes-1 and their in-edges, while
  * every other pointer still addresses the full arrays.  Used to run the edges that need no
