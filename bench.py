@@ -199,8 +199,12 @@ def main():
                            "v_mfma_f32_32x32x16_bf16, fp32 accumulate", PEAK_BF16_MFMA_TFLOPS, 6),
             }.get(mode, ("mp_edge_h4_kernel", "fp32 operands split into 2 fp16 terms (residual 2^-22), 3 partial products on "
                          "v_mfma_f32_32x32x16_f16, fp32 accumulate", PEAK_F16_MFMA_TFLOPS, 3))
-            traffic = pmc_traffic(kernel, e_kernel)
-            bytes_alg = BYTES_PER_EDGE_EDGE_KERNEL * e_kernel
+            traffic = pmc_traffic(kernel, e_kernel)          # counter pass of a launch that stores its edge latents
+            if traffic is not None:
+                traffic -= 512.0 / args.mp_steps * e_kernel  # same average over the launches as `per_edge` below
+            # the last block of the stack does not store its edge latents: average over the launches timed
+            per_edge = BYTES_PER_EDGE_EDGE_KERNEL - 512.0 / args.mp_steps
+            bytes_alg = per_edge * e_kernel
             gbs = bytes_alg / t_edge / 1e9
             t_floor_mfma = products * FLOP_PER_EDGE_EDGE_KERNEL * e_kernel / (pipe_peak * 1e12)
             t_floor_hbm = bytes_alg / (PEAK_HBM_GBS * 1e9)
@@ -213,7 +217,7 @@ def main():
             out["roofline"] = {"kernel": kernel, **roof, "traffic": traffic,
                                "traffic_unit": "bytes per launch (rocprofv3 PMC pass, see profiles/)",
                                "avg_launch_ms": kern_ms["mp_edge"],
-                               "bytes_per_edge_algorithmic": BYTES_PER_EDGE_EDGE_KERNEL,
+                               "bytes_per_edge_algorithmic": per_edge,
                                "flop_per_edge_algorithmic": FLOP_PER_EDGE_EDGE_KERNEL,
                                "fp32_equivalent_TFLOPs": ach, "fp32_equivalent_frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                                "matrix_path": path, "matrix_products_per_fp32_product": products,
