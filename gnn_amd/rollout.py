@@ -13,6 +13,7 @@ import torch
 
 from .graph import MeshGraph, batch_graphs, unbatch_nodes
 
+
 def _wants_graph(model, first, use_graph):
     """Graph replay is opt-in (``use_graph=True`` or ``MGN_ROLLOUT_GRAPH=1``): with the host-side cost
     of a launch at a few microseconds, the eager sequence of a 561-node step (0.50 ms) is no slower
@@ -26,9 +27,10 @@ class _StepGraph:
     """One rollout step -- ``predict`` plus the state feedback -- captured as a HIP graph.
 
     Replaying the captured sequence is one launch instead of ~45; it pays where the host is the
-    bottleneck (slow host cores, many small meshes driven from one thread).  What changes from step to step lives in fixed device
-    buffers: the state (fed back inside the graph), the swelling window (copied in before each
-    replay) and the normalisers' row counts (``Normalizer.use_device_count``)."""
+    bottleneck (slow host cores, many small meshes driven from one thread).  What changes from step
+    to step lives in fixed device buffers: the state (fed back inside the graph), the swelling
+    window (copied in before each replay) and the normalisers' row counts
+    (``Normalizer.use_device_count``)."""
 
     def __init__(self, model, cur):
         self.model, self.cur = model, cur
