@@ -40,6 +40,7 @@ SIGNATURES = {
     "mgn_edge_features": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_feature_sums_scratch_bytes": (_I64, [_I64, _I32]),
     "mgn_feature_sums": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
+    "mgn_feature_sums_static": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "mgn_norm_update": (C.c_int, [_P, _P, _P, _I32, _I64, _F, _P, _P]),
     "mgn_norm_update_counted": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _F, _P, _P]),
     "mgn_normalize": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),

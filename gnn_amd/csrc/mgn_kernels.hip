@@ -23,6 +23,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include "mgn_internal.h"
 
@@ -1345,6 +1346,57 @@ extern "C" int mgn_feature_sums(const float* feat, int64_t rows, int32_t n_feat,
     hipLaunchKernelGGL(feature_sums_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream,
                        (const double*)scratch, nb, (int)n_feat, sums);
     return check_launch("mgn_feature_sums");
+}
+
+// ---- the same sums with the per-block partials in a buffer the library owns: nothing is allocated
+// and no workspace is passed, for callers that cannot allocate (HIP graph capture, serving loops).
+// `scratch` is one array per GPU (every device that loads the code object holds its own copy at its
+// own address); host code never uses the array's name as an address, only the per-device pointer that
+// hipGetSymbolAddress returned with that device current.
+static __device__ __align__(256) double scratch[SUM_BLOCKS_MAX * 2 * MGN_MAX_FEAT];    // 256 KiB
+
+static std::mutex g_scratch_mu;
+static double* g_scratch_ptr[64] = {nullptr};
+
+static int scratch_of_current_device(double** out, const char* name) {
+    int dev = -1;
+    const hipError_t e0 = hipGetDevice(&dev);
+    if (e0 != hipSuccess) { mgn_set_error("%s: hipGetDevice: %s", name, hipGetErrorString(e0)); return (int)e0; }
+    if (dev < 0 || dev >= 64) { mgn_set_error("%s: device ordinal %d outside [0, 64)", name, dev); return MGN_E_RANGE; }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            mgn_set_error("%s: hipGetSymbolAddress(scratch) on device %d: %s", name, dev, hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : MGN_E_ARG;
+        }
+        g_scratch_ptr[dev] = (double*)p;
+    }
+    *out = g_scratch_ptr[dev];
+    return 0;
+}
+
+extern "C" int mgn_feature_sums_static(const float* feat, int64_t rows, int32_t n_feat, double* sums, void* stream) {
+    MGN_REQUIRE(rows >= 0 && n_feat > 0 && n_feat <= MGN_MAX_FEAT && sums, "mgn_feature_sums_static");
+    if (rows > MGN_FEATURE_SUMS_STATIC_MAX_ROWS) {
+        mgn_set_error("mgn_feature_sums_static: %lld rows exceed the limit of %lld", (long long)rows,
+                      (long long)MGN_FEATURE_SUMS_STATIC_MAX_ROWS);
+        return MGN_E_CAP;
+    }
+    MGN_REQUIRE(rows == 0 || feat, "mgn_feature_sums_static");
+    double* part = nullptr;
+    const int rc = scratch_of_current_device(&part, "mgn_feature_sums_static");
+    if (rc) return rc;
+    const int nb = sum_blocks(rows);
+    static_assert(sizeof(scratch) >= (size_t)SUM_BLOCKS_MAX * 2 * MGN_MAX_FEAT * sizeof(double), "scratch too small");
+    // every block in [0, nb) writes its columns k < F of both halves and the final kernel uses only those: whatever an
+    // earlier (larger or wider) call left in the array is never used, so nothing needs clearing between calls
+    hipLaunchKernelGGL(feature_sums_partial_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, feat,
+                       (long long)rows, (int)n_feat, part);
+    hipLaunchKernelGGL(feature_sums_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream,
+                       (const double*)part, nb, (int)n_feat, sums);
+    return check_launch("mgn_feature_sums_static");
 }
 
 extern "C" int mgn_norm_update(float* acc_sum, float* acc_sumsq, const double* sums, int32_t n_feat, int64_t count,

@@ -287,6 +287,15 @@ def feature_sums(feat, sums, scratch):
     _lib.check(rc, "mgn_feature_sums")
 
 
+def feature_sums_static(feat, sums):
+    """:func:`feature_sums` through the entry point that allocates nothing and takes no workspace (the
+    partial sums live in a buffer inside the library, one per GPU; calls overlapping on one GPU race)."""
+    m, f = feat.shape
+    rc = _lib.lib().mgn_feature_sums_static(_dev(feat, torch.float32, (m, f), "feat"), m, f,
+                                            _dev(sums, torch.float64, (2 * f,), "sums"), _stream())
+    _lib.check(rc, "mgn_feature_sums_static")
+
+
 def norm_update(acc_sum, acc_sumsq, sums, count: int, eps: float, mean_std):
     f = acc_sum.numel()
     rc = _lib.lib().mgn_norm_update(_dev(acc_sum, torch.float32, None, "acc_sum"),

@@ -140,6 +140,18 @@ int64_t mgn_feature_sums_scratch_bytes(int64_t rows, int32_t n_feat);
 int mgn_feature_sums(const float* feat, int64_t rows, int32_t n_feat, double* sums /*[2F]*/,
                      void* scratch, void* stream);
 
+/* mgn_feature_sums without a workspace argument and without any allocation: the per-block partial
+ * sums go to a 256 KiB buffer inside the library's code object (one copy per GPU, held until the
+ * process ends).  No counterpart in the reference; it exists for callers that cannot allocate or
+ * size a workspace: launch sequences under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same kernels and the same results, bit for bit, as mgn_feature_sums.
+ * rows <= MGN_FEATURE_SUMS_STATIC_MAX_ROWS, else MGN_E_CAP.  All calls on one GPU share that GPU's
+ * buffer: calls that overlap in time on one GPU (different streams) race; calls on one stream, or
+ * ordered by events, do not.  The first call on a device looks up the buffer's address
+ * (hipGetSymbolAddress) and must therefore happen outside stream capture. */
+#define MGN_FEATURE_SUMS_STATIC_MAX_ROWS ((int64_t)1 << 31)
+int mgn_feature_sums_static(const float* feat, int64_t rows, int32_t n_feat, double* sums /*[2F]*/, void* stream);
+
 /* Normalizer state update + statistics (core/normalization.py:34-35, :39-48):
  * if sums != NULL: acc_sum += (float)sums[0:F], acc_sumsq += (float)sums[F:2F];
  * then mean = acc_sum / max(count,1), std = sqrt(max(acc_sumsq/max(count,1) - mean^2, 0) + eps).
