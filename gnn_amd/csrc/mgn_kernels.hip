@@ -383,8 +383,9 @@ constexpr int PLH = TM * PKH;         // halves per fp16 plane of a 32-row tile
 // two workgroups share nothing, so one's matrix phases overlap the other's vector / LDS phases without
 // any cross-role hand-over, and a 4-wave workgroup barrier costs tens of cycles where an 8-wave one
 // costs hundreds.  Per 32-edge tile i:
-//   top   request rows / ids of tile i+1, gather ps[s] + pr[r] of tile i (registers, accumulator layout)
-//   P1    product 1 from Xp[i&1]; ReLU, split -> Hp                                    barrier B
+//   P1    product 1 from Xp[i&1], with the requests for rows / ids of tile i+1 and the gathers of ps[s], pr[r]
+//         of tile i (registers, accumulator layout) issued between its matrix instructions;
+//         ReLU, split -> Hp                                                            barrier B
 //   P2    product 2 from Hp; ReLU, LayerNorm statistics -> red                         barrier C
 //   LN    LayerNorm finish -> Os (aliases Hp, which is dead by now)                    barrier D
 //   out   split + stage tile i+1 -> Xp[(i+1)&1]; receiver-segmented scan (16 rows per thread, the two
@@ -437,20 +438,47 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
     for (int rel = 0; rel <= last; rel += TM, b ^= 1) {
         STAMP(0);
         const int nvalid = min(TM, last + 1 - rel);
-        // requests first: everything below waits only for loads that are at least a phase old
+        // This tile's gathers and the next tile's rows / ids are issued between the matrix instructions of the
+        // first product, two vector-memory loads per k-step: issued in one burst at the top, the loads of the
+        // four waves queue up in the CU's address unit and every wave stalls on the issue.  The streamed rows
+        // are marked non-temporal (read once; the gathered projections are what should stay in L2).
         f32x4 gs[4], gr[4];
-        const unsigned so = (unsigned)s_cur * H + 32 * w + 4 * h, ro = (unsigned)r_cur * H + 32 * w + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { gs[g] = *(const f32x4*)(a.ps + so + 8 * g); gr[g] = *(const f32x4*)(a.pr + ro + 8 * g); }
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            pre[it] = *(const f32x4*)(ein_g + (unsigned)(min(rel + TM + srow + 8 * it, last) * H + 4 * sq));
-        const int s_nxt = snd_g[min(rel + TM + j, last)], r_nxt = rcv_g[min(rel + TM + j, last)];
+        int s_nxt, r_nxt, rb;
         const int ra = r_cur;                                                // receiver of tile row j ...
-        const int rb = (rel + j + 1 <= last) ? rcv_g[rel + j + 1] : -1;      // ... and of the row after it
-        STAMP(1);
         f32x16 acc = zero16();
-        acc = wave_gemm_h<0, 8, 8>(Xp[b], PLH, PKH, 0, wa, j, h, acc);
+        {
+            const unsigned so = (unsigned)s_cur * H + 32 * w + 4 * h, ro = (unsigned)r_cur * H + 32 * w + 4 * h;
+            const int enx = min(rel + TM + j, last);
+            const unsigned short* r = Xp[b] + j * PKH + 8 * h;
+            u32x4 x1 = *(const u32x4*)(r), x2 = *(const u32x4*)(r + PLH);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            STAMP(1);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                u32x4 n1 = x1, n2 = x2;
+                if (c + 1 < 8) {
+                    n1 = *(const u32x4*)(r + 16 * (c + 1)); n2 = *(const u32x4*)(r + PLH + 16 * (c + 1));
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                }
+                if (c < 4) {
+                    gs[c] = *(const f32x4*)(a.ps + so + 8 * c); gr[c] = *(const f32x4*)(a.pr + ro + 8 * c);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                } else {
+                    pre[c - 4] = __builtin_nontemporal_load(
+                        (const f32x4*)(ein_g + (unsigned)(min(rel + TM + srow + 8 * (c - 4), last) * H + 4 * sq)));
+                    if (c == 4) s_nxt = snd_g[enx];
+                    if (c == 5) r_nxt = rcv_g[enx];
+                    if (c == 6) rb = (rel + j + 1 <= last) ? rcv_g[min(rel + j + 1, last)] : -1;   // ... and of the row after it
+                    if (c == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    else __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                }
+                acc = mfma32_f16(wa.p[1][c], x1, acc);   // h2 * h1
+                acc = mfma32_f16(wa.p[0][c], x2, acc);   // h1 * h2
+                acc = mfma32_f16(wa.p[0][c], x1, acc);   // h1 * h1 (the order of wave_gemm_h)
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                x1 = n1; x2 = n2;
+            }
+        }
         STAMP(2);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -506,7 +534,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = srow + 8 * it;
-                if (row < nvalid && a.e_out) *(f32x4*)(eo + (unsigned)(row * H + 4 * sq)) = y[it];
+                if (row < nvalid && a.e_out) __builtin_nontemporal_store(y[it], (f32x4*)(eo + (unsigned)(row * H + 4 * sq)));
             }
         }
         bool open = true;
