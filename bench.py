@@ -6,17 +6,25 @@
 Workload: one autoregressive rollout step (`predict`: features ->
 normalisers -> encoders -> 15 message-passing steps -> decoder -> integrator) on a synthetic
 1000 x 1000-node triangle mesh (1 000 000 nodes, 5 992 002 directed edges), latent 128, fp32,
-seeded random weights, inputs resident in HBM.  With N > 1 every rank keeps that much work: the
-mesh is 1000 x (N * 1000) nodes, partitioned by contiguous node ranges into N strips (one process
-per GPU, halo exchange of the sender projections over RCCL once per message-passing step), so
-per-GPU work is fixed ("weak" scaling).
+seeded random weights, inputs resident in HBM.  With N > 1 the SAME mesh is partitioned by
+contiguous node ranges into N strips, one process per GPU, with a halo exchange of the sender
+projections over RCCL once per message-passing step ("strong" scaling: total work fixed).
+`--scaling weak` keeps 1000 x 1000 nodes per GPU instead (a 1000 x (N * 1000) mesh).  Every
+rank builds only its own strip of the mesh.
+
+`python bench.py --gpus N` from a plain shell starts the N ranks itself (a torch.distributed.run
+child, before this process touches a GPU) and relays rank 0's line; under torch.distributed.run
+(RANK / WORLD_SIZE in the environment) it is one of the ranks.
 
 Prints ONE JSON line on rank 0.  `value` = edge updates per second over the whole job
-= E * mp_steps * K / wall time of the K timed steps (max over ranks).
+= E * mp_steps * K / wall time of the K timed steps (max over ranks).  At N = 1 the line also
+carries a `train` object: loss + backward + fused Adam on the 500 x 500 mesh with 10 blocks.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,7 +48,7 @@ def pmc_traffic(kernel, edges):
     """HBM bytes per launch of `kernel` from the committed counter pass (FETCH_SIZE and WRITE_SIZE are
     collected in separate rocprofv3 --pmc runs, which a timed run cannot do itself); scales with the
     edge count, None when no pass for this kernel is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -51,6 +59,14 @@ def pmc_traffic(kernel, edges):
     return rec["traffic_bytes_per_edge"] * edges
 
 
+def pmc_record():
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            return json.load(f)
+    except OSError:
+        return {}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -59,29 +75,110 @@ def parse():
     ap.add_argument("--grid", type=int, default=1000, help="nodes per side of the square mesh")
     ap.add_argument("--mp-steps", type=int, default=15)
     ap.add_argument("--cpu-reps", type=int, default=2, help="timed repetitions of the CPU baseline layer (0 = skip)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="N > 1: partition the fixed grid x grid mesh (strong) or keep grid x grid nodes per GPU (weak)")
+    ap.add_argument("--train-steps", type=int, default=3, help="N = 1: timed training steps for the `train` object (0 = skip)")
+    ap.add_argument("--train-grid", type=int, default=500)
+    ap.add_argument("--train-mp-steps", type=int, default=10)
     return ap.parse_args()
 
 
-def build_problem(side, mp_steps, device, world_size, rank):
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the ranks as a child job.
+    Nothing here initialises a GPU (device_count() does not), so no process that has touched one is replaced."""
+    backend = os.environ.get("MGN_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} needs {args.gpus} GPUs (one rank per GPU over RCCL), this host shows "
+                         f"{have}; MGN_DIST_BACKEND=gloo rehearses the multi-rank path with ranks sharing GPUs\n")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def make_model(mp_steps, device):
+    from gnn_amd.meshgraphnet import EncodeProcessDecodeMultiScale
+    torch.manual_seed(0)
+    return EncodeProcessDecodeMultiScale(10, 7, hidden_size=128, process_steps=mp_steps, coarse_process_steps=0,
+                                         node_out_dim=3, attention=False, with_mat_params=False, sample_ratio=0.0,
+                                         time_dim=1, device=device).to(device)
+
+
+def build_problem(side, mp_steps, device, world_size, rank, scaling):
+    """(model, full frame or None, this rank's frame on the device, plan, global nodes, global edges, mesh rows)."""
     import gnn_amd
     from gnn_amd import partition
-    from gnn_amd.meshgraphnet import EncodeProcessDecodeMultiScale
-    # one side x side block of nodes per GPU: N ranks run a side x (N * side) mesh cut into strips (weak scaling)
-    frames = gnn_amd.synthetic_frames(side - 1, side * world_size - 1, n_frames=1, seed=0)
-    g = frames[0]
+    model = make_model(mp_steps, device).eval()
+    if world_size == 1:
+        g = gnn_amd.synthetic_frames(side - 1, side - 1, n_frames=1, seed=0)[0]
+        return model, g, g.to(device), None, g["mesh_pos"].shape[0], g["edge_index"].shape[1], side
+    # every rank builds its own strip (plus one mesh row on either side), never the whole mesh
+    rows = side if scaling == "strong" else side * world_size
+    frame, in_e, out_e, n, e = gnn_amd.synthetic_strip(side - 1, rows - 1, world_size, rank, seed=0)
+    plan = partition.HaloPlan.from_local(in_e, out_e, n, e, world_size, rank).to(device)
+    partition.attach(model, plan)
+    return model, None, gnn_amd.strip_local_graph(frame, plan).to(device), plan, n, e, rows
+
+
+def train_object(args, device):
+    """Driver-visible training figure (N = 1): loss + backward + fused Adam per step on the 250k-node mesh with
+    10 blocks (the training configuration), per-kernel device time from events on the launch stream."""
+    import gnn_amd
+    from gnn_amd import ops
+    from gnn_amd.optim import FusedAdam
+    g = gnn_amd.synthetic_frames(args.train_grid - 1, args.train_grid - 1, n_frames=1, seed=0)[0]
     n, e = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
-    torch.manual_seed(0)
-    model = EncodeProcessDecodeMultiScale(10, 7, hidden_size=128, process_steps=mp_steps, coarse_process_steps=0,
-                                          node_out_dim=3, attention=False, with_mat_params=False, sample_ratio=0.0,
-                                          time_dim=1, device=device).to(device).eval()
-    plan = None
-    if world_size > 1:
-        plan = partition.HaloPlan(g["edge_index"].numpy(), n, world_size, rank).to(device)
-        partition.attach(model, plan)
-        gl = plan.local_graph(g).to(device)
-    else:
-        gl = g.to(device)
-    return model, g, gl, plan, n, e
+    gen = torch.Generator().manual_seed(1)
+    g["target"] = torch.cat([g["world_pos"], g["phi"]], -1).unsqueeze(0) + 1e-3 * torch.randn(1, n, 3, generator=gen)
+    g = g.to(device)
+    model = make_model(args.train_mp_steps, device).train()
+    opt = FusedAdam(model.parameters(), lr=1e-4, weight_decay=1e-5)
+
+    def step():
+        opt.zero_grad()
+        ls = model.loss(g)
+        ls[0].backward()
+        opt.step()
+        return ls[0]
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.train_steps
+    log = []
+    ops.set_event_log(log)
+    step()
+    torch.cuda.synchronize()
+    ops.set_event_log(None)
+    per = {}
+    for name, s0, s1 in log:
+        per.setdefault(name, []).append(s0.elapsed_time(s1))
+    kern = {k: {"calls": len(v), "ms_total": float(np.sum(v))} for k, v in per.items()}
+    out = {"metric": "training steps/s (loss forward + backward + fused Adam)", "value": 1.0 / dt, "unit": "steps/s",
+           "ms_per_step": dt * 1e3, "loss": float(last.detach()),
+           "config": {"workload": f"synthetic {args.train_grid}x{args.train_grid}-node mesh, {args.train_mp_steps} blocks, "
+                                  "loss + backward of all 136 parameters + Adam", "nodes": n, "edges": e,
+                      "mp_steps": args.train_mp_steps},
+           "edge_updates_fwd_bwd_per_s": e * args.train_mp_steps / dt, "peak_mem_GB": torch.cuda.max_memory_allocated() / 1e9,
+           "kernel_ms_one_step": kern}
+    # dominant kernel of the backward: the fused edge backward (one launch per block).  Algorithmic bytes per
+    # edge: e_in, upstream g_e read, g1 written (512 B each) + ids (8 B); gathers of ps/pr/g_aggr come from L2.
+    eb = per.get("train_edge_bwd")
+    if eb:
+        t = float(np.mean(eb)) * 1e-3
+        bytes_alg = (3 * 512 + 8) * e
+        out["roofline"] = {"kernel": "train_edge_bwd_kernel", "bound": "hbm", "achieved": bytes_alg / t / 1e9,
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_alg / t / 1e9 / PEAK_HBM_GBS,
+                           "traffic": None, "avg_launch_ms": t * 1e3, "bytes_per_edge_algorithmic": 3 * 512 + 8}
+    return out
 
 
 def cpu_baseline(g, mp_steps, reps):
@@ -112,9 +209,10 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     if args.gpus != world_size:
-        if world_size == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N (N > 1) must be launched with torch.distributed.run, one rank per GPU")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world_size}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     # MGN_DIST_BACKEND=gloo rehearses the multi-rank path on a box with fewer GPUs than ranks (ranks
@@ -131,7 +229,7 @@ def main():
             dist.init_process_group(backend)
 
     from gnn_amd import ops
-    model, g_full, g, plan, n, e = build_problem(args.grid, args.mp_steps, device, world_size, rank)
+    model, g_full, g, plan, n, e, rows = build_problem(args.grid, args.mp_steps, device, world_size, rank, args.scaling)
 
     def step(state):
         pred = model.predict(state)
@@ -179,12 +277,13 @@ def main():
             "unit": "edge-updates/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (2-term fp16 split operands, fp32 accumulate)" if os.environ.get("MGN_MATMUL", "f16x2") == "f16x2" else "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic {args.grid}x{args.grid * world_size}-node triangle mesh, one rollout step (predict) "
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (2-term fp16 split operands, fp32 accumulate)" if os.environ.get("MGN_MATMUL", "f16x2") == "f16x2" else "f32", "data": "synthetic",
+            "config": {"workload": f"synthetic {args.grid}x{rows}-node triangle mesh, one rollout step (predict) "
                                    f"= {args.mp_steps} MP steps + encoder + decoder + integrator",
                        "nodes": n, "edges": e, "mp_steps": args.mp_steps, "latent": 128,
-                       "parallelism": (f"node-range partition x{world_size} ({args.grid}x{args.grid} nodes per GPU, halo exchange "
-                                       "of the sender projections per MP step)") if world_size > 1 else "single GPU"},
+                       "parallelism": (f"node-range partition x{world_size} ({args.grid}x{rows // world_size} nodes per GPU, halo "
+                                       "exchange of the sender projections per MP step)") if world_size > 1 else "single GPU"},
+            "edge_updates_per_s_per_gpu": e * args.mp_steps * args.steps / dt / world_size,
             "rollout_steps_per_s": args.steps / dt,
             "finite": finite,
             "kernel_ms": kern_ms,
@@ -222,6 +321,8 @@ def main():
                                "fp32_equivalent_TFLOPs": ach, "fp32_equivalent_frac_of_f32_mfma_peak": ach / PEAK_F32_MFMA_TFLOPS,
                                "matrix_path": path, "matrix_products_per_fp32_product": products,
                                "matrix_pipe_frac": products * ach / pipe_peak,
+                               "matrix_pipe_busy_measured": pmc_record().get("mfma_busy_frac") if pmc_record().get("kernel") == kernel else None,
+                               "counters": {k: pmc_record().get(k) for k in ("wave_cycle_shares", "l2_hit_rate", "clock_GHz_under_profiler", "source")} if pmc_record().get("kernel") == kernel else None,
                                "floor_ms": {"hbm": t_floor_hbm * 1e3, "mfma": t_floor_mfma * 1e3}}
             # one MP step = everything the processor launches for one layer; the projection of
             # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
@@ -230,9 +331,15 @@ def main():
             canon = (FLOP_PER_EDGE_CANONICAL * e_local + FLOP_PER_NODE_CANONICAL * n_local) / t_mp / 1e12
             out["mp_step"] = {"ms": t_mp * 1e3, "edge_updates_per_s_per_gpu": e_local / t_mp,
                               "edge_updates_per_s": e / t_mp,
-                              "canonical_TFLOPs": canon, "canonical_frac_of_f32_mfma_peak": canon / PEAK_F32_MFMA_TFLOPS}
+                              "canonical_TFLOPs": canon,
+                              "compulsory_GBs": 1028.0 * (e_local + n_local) / t_mp / 1e9,
+                              "compulsory_frac_of_hbm_peak": 1028.0 * (e_local + n_local) / t_mp / 1e9 / PEAK_HBM_GBS}
         if world_size == 1 and args.cpu_reps > 0:
             out["cpu_baseline"] = cpu_baseline(g_full, args.mp_steps, args.cpu_reps)
+        if world_size == 1 and args.train_steps > 0:
+            del model, g
+            torch.cuda.empty_cache()
+            out["train"] = train_object(args, device)
         print(json.dumps(out), flush=True)
     if world_size > 1:
         import torch.distributed as dist

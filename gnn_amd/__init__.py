@@ -11,7 +11,7 @@ package does not load it, the first kernel call does and raises if it is missing
 from .graph import MeshGraph, Topology, batch_graphs, unbatch_nodes  # noqa: F401
 from .normalization import Normalizer  # noqa: F401
 from .meshgraphnet import MLP, EdgeNodeMessagePassing, EncodeProcessDecodeMultiScale  # noqa: F401
-from .datasetclass import cells_to_edge_index, grid_mesh, synthetic_frames  # noqa: F401
+from .datasetclass import cells_to_edge_index, grid_mesh, strip_local_graph, synthetic_frames, synthetic_strip  # noqa: F401
 from .rollout import rollout, rollout_batched  # noqa: F401
 
 __version__ = "0.1.0"

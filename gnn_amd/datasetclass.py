@@ -75,6 +75,74 @@ def synthetic_frames(nx: int, ny: int, n_frames: int = 1, seed: int = 0, lx: flo
     return frames
 
 
+def synthetic_strip(nx: int, ny: int, world_size: int, rank: int, seed: int = 0, lx: float = 1.0, ly: float = 1.0,
+                    time_dim: int = 1):
+    """One rank's part of a synthetic frame on the (nx+1) x (ny+1)-node grid mesh of :func:`grid_mesh`, built
+    without forming the whole mesh: the mesh rows that hold the rank's node range (as
+    :func:`gnn_amd.partition.node_bounds` cuts it) plus one row on either side.  Boundary flags as in
+    :func:`synthetic_frames`; the random state of a node depends only on (seed, its mesh row, its column), so
+    every rank -- and a single-rank run -- sees the same values for the same node.
+
+    Returns ``(frame, in_edges, out_edges, num_nodes, num_edges)``: ``frame`` holds the strip's nodes in global
+    order with ``node_ids`` (their global ids) and no ``edge_index``; ``in_edges`` / ``out_edges`` [2, .] are the
+    edge sets :meth:`gnn_amd.partition.HaloPlan.from_local` takes, in global ids; the counts are global."""
+    from .partition import node_bounds
+    w = nx + 1
+    n_total = w * (ny + 1)
+    e_total = 2 * (3 * nx * ny + nx + ny)                       # both directions of every grid side and diagonal
+    bounds = node_bounds(n_total, world_size)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    ya, yb = max(lo // w - 1, 0), min((hi - 1) // w + 1, ny)      # first and last mesh row of the strip
+    rows = yb - ya + 1
+    g0 = ya * w
+    n = rows * w
+    xs = np.linspace(0.0, lx, nx + 1)
+    ys = np.linspace(0.0, ly, ny + 1)[ya: yb + 1]
+    pos = np.empty((n, 2), dtype=np.float32)
+    pos[:, 0] = np.tile(xs, rows)
+    pos[:, 1] = np.repeat(ys, w)
+    ll = (np.arange(rows - 1)[:, None] * w + np.arange(nx)[None, :]).reshape(-1)
+    cells = np.empty((2 * nx * (rows - 1), 3), dtype=np.int64)
+    cells[0::2, 0], cells[0::2, 1], cells[0::2, 2] = ll, ll + 1, ll + nx + 2
+    cells[1::2, 0], cells[1::2, 1], cells[1::2, 2] = ll, ll + nx + 1, ll + nx + 2
+    ei = cells_to_edge_index(torch.from_numpy(cells)).numpy() + g0
+    snd, rcv = ei[0], ei[1]
+    mine = (rcv >= lo) & (rcv < hi)
+    leaving = (snd >= lo) & (snd < hi) & ~mine
+    ids = torch.arange(g0, g0 + n)
+    left, top = (ids % w) == 0, (ids // w) == ny
+    node_type = torch.zeros(n, 5)
+    node_type[left, 1] = 1.0
+    node_type[left, 2] = 1.0
+    node_type[top, 4] = 1.0
+    node_type[~(left | top), 0] = 1.0
+    mesh_pos = torch.from_numpy(pos)
+    noise = torch.empty(rows, w, 3)
+    for k in range(rows):                                       # one small generator per mesh row
+        gen = torch.Generator().manual_seed(seed * 1_000_003 + ya + k)
+        noise[k, :, :2] = torch.randn(w, 2, generator=gen)
+        noise[k, :, 2] = torch.rand(w, generator=gen)
+    noise = noise.reshape(n, 3)
+    frame = MeshGraph(mesh_pos=mesh_pos, node_type=node_type, mat_param=torch.tensor([0.2, 7.5e-6]),
+                      time=torch.tensor(0.0), world_pos=mesh_pos + 1e-3 * noise[:, :2],
+                      phi=0.5 + 0.1 * noise[:, 2:], node_ids=ids,
+                      swelling_phi=(0.35 * node_type[:, 4]).unsqueeze(1).repeat(1, time_dim + 1))
+    return frame, ei[:, mine], ei[:, leaving], n_total, e_total
+
+
+def strip_local_graph(frame: MeshGraph, plan) -> MeshGraph:
+    """The [owned | halo] rows of a :func:`synthetic_strip` frame for ``plan``, ``edge_index`` in local ids."""
+    idx = torch.from_numpy(plan.local_node_ids) - int(frame["node_ids"][0])
+    out = MeshGraph()
+    n = frame["mesh_pos"].shape[0]
+    for k, v in frame.items():
+        if k == "node_ids":
+            continue
+        out[k] = v[idx] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == n else v
+    out["edge_index"] = torch.from_numpy(plan.local_edge_index)
+    return out
+
+
 class DeviceTrajectory:
     """One trajectory resident on the GPU; frames are views of it.
 

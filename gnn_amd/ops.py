@@ -51,6 +51,21 @@ class timed:
         return False
 
 
+def _timed_op(fn):
+    """Wraps a kernel wrapper so that its launches are logged under its own name while an event log is
+    installed (no cost otherwise beyond one comparison)."""
+    import functools
+    name = fn.__name__
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        if _event_log is None:
+            return fn(*args, **kwargs)
+        with timed(name):
+            return fn(*args, **kwargs)
+    return wrapper
+
+
 def _stream() -> int:
     """Raw handle of torch's current HIP stream."""
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
@@ -396,6 +411,7 @@ def _wblock(w, koff, name):
     return p
 
 
+@_timed_op
 def train_linear_fwd(a, w, koff_a, out, b=None, koff_b=0, bias=None, p=None, idx_p=None, q=None, idx_q=None,
                      relu=False):
     rows = a.shape[0]
@@ -411,6 +427,7 @@ def train_linear_fwd(a, w, koff_a, out, b=None, koff_b=0, bias=None, p=None, idx
     _lib.check(rc, "mgn_train_linear_fwd")
 
 
+@_timed_op
 def train_ln_fwd(v, gamma, beta, y=None, res=None, yres=None):
     rows = v.shape[0]
     if (y is None and yres is None) or ((yres is None) != (res is None)):
@@ -429,6 +446,7 @@ def _scratch(scratch):
     return p
 
 
+@_timed_op
 def train_ln_bwd(v, gamma, gpre, dgamma, dbeta, scratch, g=None, gg=None, idx=None, relu_mask=False):
     rows = v.shape[0]
     if g is None and gg is None:
@@ -443,6 +461,7 @@ def train_ln_bwd(v, gamma, gpre, dgamma, dbeta, scratch, g=None, gg=None, idx=No
     _lib.check(rc, "mgn_train_ln_bwd")
 
 
+@_timed_op
 def train_linear_bwd(g, scratch, a=None, w=None, koff=0, mask=None, res=None, ga=None, dw=None, dw_koff=0, db=None):
     """``dw`` is the full [128, ld] gradient tensor; its columns dw_koff .. dw_koff+127 are written."""
     rows = g.shape[0]
@@ -467,6 +486,7 @@ def train_linear_bwd(g, scratch, a=None, w=None, koff=0, mask=None, res=None, ga
     _lib.check(rc, "mgn_train_linear_bwd")
 
 
+@_timed_op
 def train_edge_bwd(e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, ln_w, g1, dpr, dw1, db1, dgamma, dbeta,
                    scratch):
     """Fused backward of one block's edge MLP with recomputed hidden activations (default matrix path)."""
@@ -483,6 +503,7 @@ def train_edge_bwd(e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, 
     _lib.check(rc, "mgn_train_edge_bwd")
 
 
+@_timed_op
 def segment_sum(src, rowptr, out, order=None):
     n = out.shape[0]
     _dev(rowptr, torch.int32, (n + 1,), "rowptr")
@@ -491,6 +512,7 @@ def segment_sum(src, rowptr, out, order=None):
     _lib.check(rc, "mgn_segment_sum")
 
 
+@_timed_op
 def train_pad_features(feat, mean_std, out):
     rows, f = feat.shape
     if f > H:
@@ -501,6 +523,7 @@ def train_pad_features(feat, mean_std, out):
     _lib.check(rc, "mgn_train_pad_features")
 
 
+@_timed_op
 def train_loss_fwd(decoded, target_norm, node_type, time_dim, loss3, scratch):
     n = decoded.shape[0]
     rc = _lib.lib().mgn_train_loss_fwd(_rows128(decoded, "decoded"),
@@ -510,6 +533,7 @@ def train_loss_fwd(decoded, target_norm, node_type, time_dim, loss3, scratch):
     _lib.check(rc, "mgn_train_loss_fwd")
 
 
+@_timed_op
 def train_loss_bwd(decoded, target_norm, node_type, grad3, time_dim, gdecoded):
     n = decoded.shape[0]
     rc = _lib.lib().mgn_train_loss_bwd(_rows128(decoded, "decoded"),

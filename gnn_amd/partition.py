@@ -32,15 +32,38 @@ class HaloPlan:
     """Everything rank ``rank`` needs to run its share of a partitioned mesh."""
 
     def __init__(self, edge_index: np.ndarray, num_nodes: int, world_size: int, rank: int):
+        """From the global edge list (every rank scans all of it; use :meth:`from_local` when a rank can
+        produce its own part of the mesh)."""
         ei = np.asarray(edge_index, dtype=np.int64)
-        self.world_size, self.rank, self.global_nodes, self.global_edges = world_size, rank, int(num_nodes), int(ei.shape[1])
+        bounds = node_bounds(num_nodes, world_size)
+        lo, hi = bounds[rank], bounds[rank + 1]
+        snd, rcv = ei[0], ei[1]
+        mine = (rcv >= lo) & (rcv < hi)
+        leaving = (snd >= lo) & (snd < hi) & ~mine
+        self._build(ei[:, mine], np.nonzero(mine)[0], ei[:, leaving], int(num_nodes), int(ei.shape[1]), world_size, rank)
+
+    @classmethod
+    def from_local(cls, in_edges: np.ndarray, out_edges: np.ndarray, num_nodes: int, num_edges: int, world_size: int,
+                   rank: int, in_edge_ids: Optional[np.ndarray] = None) -> "HaloPlan":
+        """From the two edge sets a rank can list without seeing the whole mesh, in global node ids:
+        ``in_edges`` [2, .] = every edge whose receiver the rank owns, in the order of the global edge
+        list; ``out_edges`` [2, .] = every edge whose sender it owns and whose receiver it does not.
+        ``num_nodes`` / ``num_edges`` are the global counts."""
+        plan = cls.__new__(cls)
+        plan._build(np.asarray(in_edges, dtype=np.int64),
+                    None if in_edge_ids is None else np.asarray(in_edge_ids, dtype=np.int64),
+                    np.asarray(out_edges, dtype=np.int64), int(num_nodes), int(num_edges), world_size, rank)
+        return plan
+
+    def _build(self, in_edges, in_edge_ids, out_edges, num_nodes, num_edges, world_size, rank):
+        self.world_size, self.rank, self.global_nodes, self.global_edges = world_size, rank, num_nodes, num_edges
         self.bounds = node_bounds(num_nodes, world_size)
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
-        snd, rcv = ei[0], ei[1]
         owner_of = lambda ids: np.searchsorted(np.asarray(self.bounds[1:]), ids, side="right")
-        mine = (rcv >= lo) & (rcv < hi)
-        self.edge_ids = np.nonzero(mine)[0]                       # global positions of the local edges
-        ls, lr = snd[mine], rcv[mine]
+        ls, lr = in_edges[0], in_edges[1]
+        if ls.size and (lr.min() < lo or lr.max() >= hi):
+            raise ValueError("HaloPlan: an in-edge's receiver lies outside the rank's node range")
+        self.edge_ids = in_edge_ids                               # global positions of the local edges (None if unknown)
         outside = (ls < lo) | (ls >= hi)
         self.halo_ids = np.unique(ls[outside])                    # global ids, ascending => grouped by owner
         self.num_owned, self.num_halo = hi - lo, int(self.halo_ids.shape[0])
@@ -53,10 +76,9 @@ class HaloPlan:
         self.recv_counts = [int((halo_owner == q).sum()) for q in range(world_size)]
         # what every peer q needs from this rank: q's halo nodes that fall into [lo, hi)
         send_ids, self.send_counts = [], []
-        src_owner = owner_of(snd)
-        dst_owner = owner_of(rcv)
-        cross = np.nonzero((src_owner == rank) & (dst_owner != rank))[0]       # edges leaving this rank: few
-        cross_snd, cross_dst = snd[cross], dst_owner[cross]
+        cross_snd, cross_dst = out_edges[0], owner_of(out_edges[1])
+        if cross_snd.size and (cross_snd.min() < lo or cross_snd.max() >= hi or (cross_dst == rank).any()):
+            raise ValueError("HaloPlan: out-edges must lead from an owned sender to a receiver of another rank")
         for q in range(world_size):
             if q == rank:
                 self.send_counts.append(0)
@@ -155,7 +177,7 @@ class HaloPlan:
 
         if async_op:
             return _Pending()
-        self._add_returned(buf, recv)
+        _Pending().wait()                         # the host-staged transport hands back a handle in both modes
         return buf
 
     def _add_returned(self, buf: torch.Tensor, recv: torch.Tensor) -> None:

@@ -134,7 +134,8 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
             # whole edge update in one kernel; hidden activations are recomputed in the backward
             aggr = torch.zeros(n, H, dtype=torch.float32, device=dev)     # receivers without in-edges stay 0
             e_next = None if last else _empty(e, dev)      # the edge latents after the last block are unused
-            ops.mp_edge(el, ps, pr, topo.rowptr, topo.sender, topo.recv, em.weights(), e_next, aggr)
+            with ops.timed("mp_edge"):
+                ops.mp_edge(el, ps, pr, topo.rowptr, topo.sender, topo.recv, em.weights(), e_next, aggr)
             h1e = ve = None
             if keep_hidden:
                 h1e, ve = _empty(e, dev), _empty(e, dev)

@@ -157,6 +157,10 @@ def _worker(rank, world, port, ret):
         if pend is not None:
             pend.wait()
         summed = plan.gather_owned(contrib[: plan.num_owned].contiguous())
+        # the same through the synchronous form
+        contrib2 = torch.from_numpy(plan.local_node_ids).double().reshape(-1, 1) * torch.tensor([[1.0, 0.5]], dtype=torch.float64) * (rank + 1)
+        plan.return_rows(contrib2)
+        sync_same = bool(torch.equal(contrib2[: plan.num_owned], contrib[: plan.num_owned]))
         tot = plan.all_reduce_(torch.tensor([float(rank + 1)]))
         from gnn_amd.partition import all_reduce_gradients
         lin = torch.nn.Linear(3, 2)
@@ -164,6 +168,7 @@ def _worker(rank, world, port, ret):
             prm.grad = torch.full_like(prm, float(rank + 1))
         all_reduce_gradients(lin)                                 # replicas: averaged gradients
         avg_ok = all(torch.equal(prm.grad, torch.full_like(prm, (world + 1) / 2)) for prm in lin.parameters())
+        ret[f"sync_same_{rank}"] = sync_same
         if rank == 0:
             ret["avg_ok"] = avg_ok
             expect = torch.zeros(n, 2, dtype=torch.float64)
@@ -191,5 +196,34 @@ def test_two_rank_halo_exchange_matches_full_mesh():
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret["count_ok"]
     assert ret["return_rows_ok"] and ret["all_reduce_ok"] and ret["avg_ok"]
+    assert ret["sync_same_0"] and ret["sync_same_1"]
     assert ret["sum_rel"] < 1e-6
     assert ret["rel"] < 2e-5, ret["rel"]
+
+
+def test_plan_from_a_rank_local_strip_equals_plan_from_the_global_edge_list():
+    """``synthetic_strip`` builds only the mesh rows around a rank's node range; the plan made from its two edge
+    sets must be the plan made from the whole mesh, and the strip's fields the global fields of the same nodes."""
+    import gnn_amd
+    from gnn_amd.partition import HaloPlan
+    nx, ny = 13, 11
+    full, in_all, out_all, n_total, e_total = gnn_amd.synthetic_strip(nx, ny, 1, 0)
+    pos, cells = gnn_amd.grid_mesh(nx, ny)
+    ei = gnn_amd.cells_to_edge_index(torch.from_numpy(cells)).numpy()
+    assert np.array_equal(in_all, ei) and out_all.shape[1] == 0 and (n_total, e_total) == (pos.shape[0], ei.shape[1])
+    for world in (2, 3, 5, 12):
+        for rank in range(world):
+            frame, in_e, out_e, n2, e2 = gnn_amd.synthetic_strip(nx, ny, world, rank)
+            assert (n2, e2) == (n_total, e_total)
+            assert frame["mesh_pos"].shape[0] < n_total or world == 2         # a strip, not the mesh
+            local, glob = HaloPlan.from_local(in_e, out_e, n2, e2, world, rank), HaloPlan(ei, n_total, world, rank)
+            assert np.array_equal(local.local_edge_index, glob.local_edge_index)
+            assert np.array_equal(local.local_node_ids, glob.local_node_ids)
+            assert np.array_equal(local.send_local_ids, glob.send_local_ids)
+            assert local.send_counts == glob.send_counts and local.recv_counts == glob.recv_counts
+            gl = gnn_amd.strip_local_graph(frame, local)
+            ids = torch.from_numpy(local.local_node_ids)
+            for k in ("world_pos", "phi", "node_type", "mesh_pos", "swelling_phi"):
+                assert torch.equal(gl[k], full[k][ids]), k
+    with pytest.raises(ValueError):
+        HaloPlan.from_local(ei, np.zeros((2, 0), dtype=np.int64), n_total, e_total, 2, 0)   # receivers of rank 1 among the in-edges
