@@ -26,6 +26,9 @@ _MLP = C.POINTER(MgnMlp)
 SIGNATURES = {
     "mgn_abi_version": (C.c_int, []),
     "mgn_last_error": (C.c_char_p, []),
+    "mgn_get_matmul_mode": (C.c_int, []),
+    "mgn_set_matmul_mode": (C.c_int, [C.c_int]),
+    "mgn_range_check": (C.c_int, [_P, _I32, _P]),
     "mgn_cells_to_edge_index": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _P]),
     "mgn_receiver_csr": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
     "mgn_edge_build_workspace_bytes": (C.c_int64, [_I64]),

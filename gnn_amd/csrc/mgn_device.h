@@ -211,6 +211,21 @@ __device__ __forceinline__ void split2_pack4(const f32x4 v, u32x2& p1, u32x2& p2
     p1 = u32x2{a1, b1}; p2 = u32x2{a2, b2};
 }
 
+// Range guard of the split: a value of 65520 or more rounds to an fp16 infinity, and what follows is silently wrong
+// (inf - inf = NaN, and the ReLUs turn NaN into 0).  Every thread keeps the largest magnitude it has split
+// (two values per v_max3_f32) and raises a sticky per-GPU flag at the end of the kernel; the host reads it with
+// mgn_range_check().  One flag per translation unit of the library.
+constexpr float F16_SPLIT_LIMIT = 65520.0f;
+static __device__ unsigned g_range_flag = 0;
+
+__device__ __forceinline__ void track4(float& m, const f32x4 v) {
+    m = fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1])));
+    m = fmaxf(m, fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ void range_report(float m) {
+    if (m >= F16_SPLIT_LIMIT) atomicOr(&g_range_flag, 1u);
+}
+
 // A tile of `rows` x K fp16 in two planes: plane p, row r, column k at  p * plane + r * ld + k  (halves),
 // ld = K + 8 (16 bytes of padding per row keep the 16-byte reads of 16 consecutive rows on distinct banks).
 __device__ __forceinline__ void hplanes_store4(unsigned short* tile, int plane, int ld, int row, int k, const f32x4 v) {
@@ -218,6 +233,11 @@ __device__ __forceinline__ void hplanes_store4(unsigned short* tile, int plane, 
     split2_pack4(v, p1, p2);
     unsigned short* d = tile + row * ld + k;
     *(u32x2*)(d) = p1; *(u32x2*)(d + plane) = p2;
+}
+
+__device__ __forceinline__ void hplanes_store4(unsigned short* tile, int plane, int ld, int row, int k, const f32x4 v, float& m) {
+    track4(m, v);
+    hplanes_store4(tile, plane, ld, row, k, v);
 }
 
 // Register-resident fp16 planes of the weights of 32 output features over 16*KS inputs
@@ -228,15 +248,18 @@ struct WPlanesH { u32x4 p[2][KS]; };
 template <int KS>
 __device__ __forceinline__ void load_wplanes_h(WPlanesH<KS>& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
     const float* row = W + (size_t)feat * ldw + koff + 8 * h;
+    float m = 0.f;
 #pragma unroll
     for (int c = 0; c < KS; ++c) {
         const f32x4 lo4 = *(const f32x4*)(row + 16 * c) * W_SCALE, hi4 = *(const f32x4*)(row + 16 * c + 4) * W_SCALE;
+        track4(m, lo4); track4(m, hi4);
         u32x2 a1, a2, b1, b2;
         split2_pack4(lo4, a1, a2);
         split2_pack4(hi4, b1, b2);
         w.p[0][c] = u32x4{a1[0], a1[1], b1[0], b1[1]};
         w.p[1][c] = u32x4{a2[0], a2[1], b2[0], b2[1]};
     }
+    range_report(m);                                // a weight of 512 or more (after the pre-scale) is out of range too
 }
 
 __device__ __forceinline__ f32x16 mfma32_f16(u32x4 a, u32x4 b, f32x16 c) {
@@ -439,6 +462,21 @@ inline int grid_for(long long ntiles, int per_cu) {
     if (ntiles < g) g = ntiles;
     if (g > 8) g -= g % 8;
     return (int)(g < 1 ? 1 : g);
+}
+
+// reads (and optionally clears) this translation unit's range flag of the current device; synchronises `stream`
+inline int read_range_flag(int* tripped, int reset, hipStream_t stream, const char* name) {
+    unsigned v = 0;
+    hipError_t e = hipMemcpyFromSymbolAsync(&v, HIP_SYMBOL(g_range_flag), sizeof(v), 0, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess && reset && v) {
+        const unsigned z = 0;
+        e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_range_flag), &z, sizeof(z), 0, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    if (e != hipSuccess) { mgn_set_error("%s: %s", name, hipGetErrorString(e)); return (int)e; }
+    *tripped |= (int)(v != 0);
+    return 0;
 }
 
 inline int check_launch(const char* what) {

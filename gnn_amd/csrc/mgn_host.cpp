@@ -124,11 +124,25 @@ extern "C" int mgn_receiver_csr(const int64_t* sender, const int64_t* recv, int6
     return 0;
 }
 
+static int g_matmul_mode = -1;
+
 int mgn_matmul_mode() {
-    static int mode = -1;
-    if (mode < 0) {
+    if (g_matmul_mode < 0) {
         const char* e = getenv("MGN_MATMUL");
-        mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "bf16x3")) ? 1 : 2;
+        g_matmul_mode = (e && !strcmp(e, "f32")) ? 0 : (e && !strcmp(e, "bf16x3")) ? 1 : 2;
     }
-    return mode;
+    return g_matmul_mode;
+}
+
+void mgn_set_matmul_mode_internal(int mode) { g_matmul_mode = mode; }
+
+extern "C" int mgn_get_matmul_mode(void) { return mgn_matmul_mode(); }
+
+extern "C" int mgn_set_matmul_mode(int mode) {
+    if (mode < 0 || mode > 2) {
+        mgn_set_error("mgn_set_matmul_mode: mode %d is not one of MGN_MATMUL_F32 (0), MGN_MATMUL_BF16X3 (1), MGN_MATMUL_F16X2 (2)", mode);
+        return MGN_E_ARG;
+    }
+    g_matmul_mode = mode;
+    return 0;
 }

@@ -430,8 +430,9 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) cur[it] = *(const f32x4*)(ein_g + (unsigned)(min(srow + 8 * it, last) * H + 4 * sq));
     int s_cur = snd_g[min(j, last)], r_cur = rcv_g[min(j, last)];
+    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) hplanes_store4(Xp[0], PLH, PKH, srow + 8 * it, 4 * sq, cur[it]);
+    for (int it = 0; it < 4; ++it) hplanes_store4(Xp[0], PLH, PKH, srow + 8 * it, 4 * sq, cur[it], rmax);
     __syncthreads();
     STAMP_DECL
     int b = 0;
@@ -485,7 +486,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
             f32x4 v;
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[k] = fmaxf(fmaf(acc[4 * g + k], W_UNSCALE, gs[g][k] + gr[g][k]), 0.f);
-            hplanes_store4(Hp, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
+            hplanes_store4(Hp, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v, rmax);
         }
         STAMP(3);
         __syncthreads();                                                     // (B) hidden tile complete
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
         STAMP(8);
         // next tile into the other plane buffer (its rows were requested at the top of this pass)
 #pragma unroll
-        for (int it = 0; it < 4; ++it) hplanes_store4(Xp[b ^ 1], PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);
+        for (int it = 0; it < 4; ++it) hplanes_store4(Xp[b ^ 1], PLH, PKH, srow + 8 * it, 4 * sq, pre[it], rmax);
         STAMP(9);
         // receiver-segmented sum: thread (column sc, group sg) scans rows 16sg .. 16sg+15 in order;
         // xr[r] = sum of the rows since the last segment end before r
@@ -553,6 +554,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) cur[it] = pre[it];
     }
+    range_report(rmax);
     STAMP_FLUSH(w == 0 ? 0 : (w == 2 ? 1 : -1))
 }
 
@@ -729,10 +731,11 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         }
         return acc;
     };
+    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
     auto planes_from_acc = [&](unsigned short* tile, const f32x16& v) {
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            hplanes_store4(tile, PL, PKH, j, 32 * w + 8 * g + 4 * h, f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]});
+            hplanes_store4(tile, PL, PKH, j, 32 * w + 8 * g + 4 * h, f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, rmax);
     };
     prefetch(t0);
     __syncthreads();
@@ -744,8 +747,8 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it;
             *(f32x4*)(Xf + toff(row, sq, H / 4)) = px[it];
-            hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it]);
-            hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it]);
+            hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it], rmax);
+            hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it], rmax);
         }
         STAMP(1);
         __syncthreads();                                             // (1) tile staged
@@ -805,6 +808,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         // Xf / XAp are rewritten at the top of the next pass, after every thread's last read of them
         // (before barrier 4 resp. 2); Os / Ps / Pr are rewritten only after the next pass's barriers
     }
+    range_report(rmax);
     if constexpr (PROJ) { STAMP_FLUSH(w == 0 ? 0 : (w == 2 ? 1 : -1)) }
 }
 
@@ -836,6 +840,7 @@ __global__ __launch_bounds__(NT, 2) void mp_project_kernel(ProjArgs a) {
     const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
     const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
     const int srow = t >> 5, sq = t & 31;
+    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
     __syncthreads();
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(NT, 2) void mp_project_kernel(ProjArgs a) {
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it, n = min(base + row, a.n_nodes - 1);
             const f32x4 v = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
-            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, v);
+            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, v, rmax);
             else *(f32x4*)(X + toff(row, sq, H / 4)) = v;
         }
         __syncthreads();
@@ -870,6 +875,7 @@ __global__ __launch_bounds__(NT, 2) void mp_project_kernel(ProjArgs a) {
         }
         __syncthreads();
     }
+    if constexpr (HALF) range_report(rmax);
 }
 
 // ======================================================================== encoder
@@ -1022,6 +1028,7 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
     const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
     const int srow = t >> 5, sq = t & 31;
     f32x4 pre[4];                                    // rows of the next tile, requested one pass ahead
+    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
     if (t0 < t1) {
 #pragma unroll
         for (int it = 0; it < 4; ++it)
@@ -1033,7 +1040,7 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it;
-            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, pre[it]);
+            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, pre[it], rmax);
             else *(f32x4*)(X + toff(row, sq, H / 4)) = pre[it];
         }
         __syncthreads();
@@ -1050,7 +1057,7 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
                 f32x4 v;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) v[k] = fmaxf(acc[4 * g + k] * US, 0.f);
-                hplanes_store4(Hq, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
+                hplanes_store4(Hq, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v, rmax);
             }
         } else {
             acc = wave_gemm<16>(X, H / 4, 0, wa, j, h, acc);
@@ -1083,6 +1090,7 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
         }
         __syncthreads();
     }
+    if constexpr (HALF) range_report(rmax);
 }
 
 // ======================================================================== features / normaliser
@@ -1425,6 +1433,15 @@ extern "C" int mgn_feature_sums_static(const float* feat, int64_t rows, int32_t 
     hipLaunchKernelGGL(feature_sums_final_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream,
                        (const double*)part, nb, (int)n_feat, sums);
     return check_launch("mgn_feature_sums_static");
+}
+
+extern "C" int mgn_range_check(int32_t* tripped, int32_t reset, void* stream) {
+    MGN_REQUIRE(tripped, "mgn_range_check");
+    int t = 0;
+    int rc = read_range_flag(&t, reset, (hipStream_t)stream, "mgn_range_check");
+    if (rc == 0) rc = mgn_train_read_range_flag(&t, reset, stream);
+    if (rc == 0) *tripped = t;
+    return rc;
 }
 
 extern "C" int mgn_norm_update(float* acc_sum, float* acc_sumsq, const double* sums, int32_t n_feat, int64_t count,

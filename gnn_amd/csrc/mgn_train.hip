@@ -75,6 +75,7 @@ __global__ __launch_bounds__(NT, 2) void train_linear_fwd_kernel(LinFwdArgs a) {
     int t0, t1;
     tile_range(a.rows, t0, t1);
     const int srow = t >> 5, sq = t & 31;
+    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
     __syncthreads();
     for (int tile = t0; tile < t1; ++tile) {
         const long long base = (long long)tile * TM;
@@ -84,11 +85,11 @@ __global__ __launch_bounds__(NT, 2) void train_linear_fwd_kernel(LinFwdArgs a) {
             const int row = srow + 8 * it;
             const long long n = min(base + row, a.rows - 1);
             const f32x4 va = *(const f32x4*)(a.A + n * H + 4 * sq);
-            if constexpr (HALF) hplanes_store4(Xs, PLN, LDH, row, 4 * sq, va);
+            if constexpr (HALF) hplanes_store4(Xs, PLN, LDH, row, 4 * sq, va, rmax);
             else *(f32x4*)(X + toff(row, sq, K4)) = va;
             if constexpr (TWO) {
                 const f32x4 vb = *(const f32x4*)(a.B + n * H + 4 * sq);
-                if constexpr (HALF) hplanes_store4(Xs, PLN, LDH, row, H + 4 * sq, vb);
+                if constexpr (HALF) hplanes_store4(Xs, PLN, LDH, row, H + 4 * sq, vb, rmax);
                 else *(f32x4*)(X + toff(row, 32 + sq, K4)) = vb;
             }
         }
@@ -125,6 +126,7 @@ __global__ __launch_bounds__(NT, 2) void train_linear_fwd_kernel(LinFwdArgs a) {
         // the tile is restaged at the top of the next pass: every wave has finished its products before
         // the barrier above; O is rewritten only after the next pass's first barrier
     }
+    if constexpr (HALF) range_report(rmax);
 }
 
 // ------------------------------------------------------------------------ LayerNorm forward
@@ -947,6 +949,10 @@ extern "C" int mgn_debug_read_train_stamps(unsigned long long* out32, int reset)
     return 0;
 }
 #endif
+
+int mgn_train_read_range_flag(int* tripped, int reset, void* stream) {
+    return read_range_flag(tripped, reset, (hipStream_t)stream, "mgn_range_check");
+}
 
 extern "C" int64_t mgn_train_scratch_bytes(void) {
     return (int64_t)TRAIN_BLOCKS_MAX * PARTIAL * (int64_t)sizeof(float);

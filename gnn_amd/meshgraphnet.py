@@ -299,11 +299,16 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         n = halo.num_owned if halo is not None else topo.num_nodes
         delta = torch.empty(self.time_dim, n, self.node_out_dim, dtype=torch.float32, device=ws.x.device)
         ops.decode(ws.x[:n], self.node_decoder.weights(), self.time_dim, self.node_out_dim, delta_norm=delta)
+        ops.raise_if_out_of_range("forward")
         return delta
 
-    def predict(self, graph):
+    def predict(self, graph, check_range: bool = True):
         """Next state(s) [time_dim, N, 3]: decode, de-normalise, zero the deltas of
-        Dirichlet nodes, add to the current state (core/meshgraphnet.py:305-317)."""
+        Dirichlet nodes, add to the current state (core/meshgraphnet.py:305-317).
+
+        ``check_range``: read the range flag of the default matrix path after the launches (one small
+        device-to-host copy, which waits for the step) and raise if an operand left the fp16 range; loops
+        that check once at their end (``rollout``) pass False."""
         if self.node_out_dim != 3:
             raise RuntimeError("predict: node_out_dim must be 3 (world_pos x, y and phi)")
         with torch.no_grad():
@@ -315,6 +320,8 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             ops.decode(ws.x[:n], self.node_decoder.weights(), self.time_dim, 3, out_mean_std=ms_o,
                        world_pos=self._f32(graph["world_pos"])[:n], phi=self._f32(graph["phi"])[:n],
                        node_type=self._f32(graph["node_type"])[:n], pred=pred)
+        if check_range:
+            ops.raise_if_out_of_range("predict")
         return pred
 
     def _normalized_target(self, graph) -> torch.Tensor:
@@ -351,6 +358,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             comps = training.loss_components(self, graph, tgt)
         else:
             comps, _ = training.forward_saving(self, graph, tgt)
+        ops.raise_if_out_of_range("loss")
         return comps[0] + comps[1] + comps[2], comps[0], comps[1], comps[2]
 
     def save_model(self, path):

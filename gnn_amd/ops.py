@@ -387,12 +387,41 @@ def scatter_rows(src, idx, dst):
 
 
 # --------------------------------------------------------------------------- device: training blocks
+_MODES = ("f32", "bf16x3", "f16x2")
+
+
 def matmul_mode() -> str:
-    """The matrix path libmgn_hip.so selects from the environment (MGN_MATMUL): "f16x2" (default),
-    "bf16x3" or "f32"."""
-    import os
-    v = os.environ.get("MGN_MATMUL", "")
-    return v if v in ("f32", "bf16x3") else "f16x2"
+    """The matrix path the library is using: "f16x2" (default), "bf16x3" or "f32" (initially from the
+    environment variable MGN_MATMUL, read by the library at its first call)."""
+    return _MODES[_lib.lib().mgn_get_matmul_mode()]
+
+
+def set_matmul_mode(mode: str) -> str:
+    """Switches the matrix path of all later launches in this process; returns the previous one.  A forward
+    pass and its backward pass must run under the same mode."""
+    if mode not in _MODES:
+        raise ValueError(f"matmul mode must be one of {_MODES}, got {mode!r}")
+    prev = matmul_mode()
+    _lib.check(_lib.lib().mgn_set_matmul_mode(_MODES.index(mode)), "mgn_set_matmul_mode")
+    return prev
+
+
+def range_check(reset: bool = True) -> bool:
+    """True if a kernel on the current device fed the fp16 split an operand of 65520 or more since the last
+    reset (the results of that launch chain are then wrong).  Synchronises the current stream."""
+    v = C.c_int32(0)
+    _lib.check(_lib.lib().mgn_range_check(C.addressof(v), 1 if reset else 0, _stream()), "mgn_range_check")
+    return bool(v.value)
+
+
+def raise_if_out_of_range(what: str):
+    """Raises when the fp16-split path saw an operand beyond its range during ``what``."""
+    if matmul_mode() == "f16x2" and range_check(reset=True):
+        raise RuntimeError(
+            f"{what}: an activation or weight reached the range limit of the default matrix path (operands are split "
+            "into two fp16 terms: |value| must stay below 65520, weights below 512); the results of this call are "
+            "invalid.  Rerun with the environment variable MGN_MATMUL=bf16x3 (or gnn_amd.ops.set_matmul_mode('bf16x3')), "
+            "which has no range limit.")
 
 
 def train_scratch_bytes() -> int:

@@ -54,7 +54,7 @@ class _StepGraph:
             nr._acc_count, nr._num_accumulations = c, k
 
     def _body(self):
-        pred = self.model.predict(self.cur)
+        pred = self.model.predict(self.cur, check_range=False)
         last = pred[-1]
         self.cur["world_pos"].copy_(last[:, :2])
         self.cur["phi"].copy_(last[:, 2:])
@@ -124,7 +124,7 @@ def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
                     preds.append(captured.step().clone())
                     continue
                 cur["swelling_phi"] = sched[t: t + time_dim + 1].T.contiguous()
-                pred = model.predict(cur)
+                pred = model.predict(cur, check_range=False)       # checked once, after the loop
                 last = pred[-1]
                 cur["world_pos"] = last[:, :2].contiguous()
                 cur["phi"] = last[:, 2:].contiguous()
@@ -132,6 +132,8 @@ def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
         finally:
             if captured is not None:
                 captured.close()
+        from . import ops
+        ops.raise_if_out_of_range("rollout")
         rollout_preds = torch.cat(preds, dim=0)[:n_frames]
         rollout_gts = torch.stack([torch.cat([data[t]["world_pos"], data[t]["phi"]], dim=-1)
                                    for t in range(n_frames)]).to(device)

@@ -10,7 +10,9 @@
  *     failed, or a negative MGN_E_* code; mgn_last_error() then holds a message
  *     (thread-local).
  *   - All device pointers are borrowed for the duration of the call.  The library
- *     allocates no device memory and keeps no state between calls.
+ *     allocates no device memory.  Its only state between calls: the matrix path
+ *     (mgn_set_matmul_mode), the sticky range flag (mgn_range_check) and the partial-sum
+ *     buffer of mgn_feature_sums_static.
  *   - Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
  *     stream) and the call returns without synchronising.
  *   - Latent width is fixed at MGN_H = 128 (hidden_size of every shipped config).
@@ -51,6 +53,26 @@ typedef struct mgn_mlp {
 
 int mgn_abi_version(void);
 const char* mgn_last_error(void);
+
+/* Matrix path of the MLP kernels, one setting per process: MGN_MATMUL_F16X2 (default; fp32 operands as two fp16
+ * terms, three partial products), MGN_MATMUL_BF16X3 (three bf16 terms, six partial products) or MGN_MATMUL_F32
+ * (fp32 matrix instructions).  All meet the same fp32 tolerance against core/meshgraphnet.py:33-120; the first is
+ * the fastest and needs every operand below 65520 in magnitude (weights below 512), see mgn_range_check.  The
+ * initial value comes from the environment variable MGN_MATMUL = f16x2 | bf16x3 | f32, read at the first call.
+ * A forward pass and the backward pass that belongs to it must run under the same setting. */
+#define MGN_MATMUL_F32    0
+#define MGN_MATMUL_BF16X3 1
+#define MGN_MATMUL_F16X2  2
+int mgn_get_matmul_mode(void);
+int mgn_set_matmul_mode(int mode);
+
+/* Range guard of MGN_MATMUL_F16X2.  The reference computes in fp32 and has no such limit (core/meshgraphnet.py
+ * :33-120); here an operand of 65520 or more would round to an fp16 infinity and the result would be silently
+ * wrong, so the kernels that split operands raise a sticky per-GPU flag instead.  *tripped = 1 if any launch on
+ * the current device since the last reset saw such an operand (activations, gathered rows, hidden activations,
+ * weights after their pre-scale of 128), else 0; reset != 0 clears the flag.  Synchronises `stream`.  Callers
+ * check once per forward pass or rollout and switch to MGN_MATMUL_BF16X3 (no range limit) when it trips. */
+int mgn_range_check(int32_t* tripped /*host*/, int32_t reset, void* stream);
 
 /* ---- host side: edge build (integer work, bit-exact) ------------------------------
  * cells_to_edge_index, core/datasetclass.py:7-20, including what PyG 2.6.1

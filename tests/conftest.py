@@ -24,3 +24,12 @@ def rel_l2(a, b):
     import torch
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+@pytest.fixture(params=["f16x2", "bf16x3", "f32"])
+def matmul_mode(request):
+    """Runs the test once per matrix path of the library (switched in this process, restored afterwards)."""
+    from gnn_amd import ops
+    prev = ops.set_matmul_mode(request.param)
+    yield request.param
+    ops.set_matmul_mode(prev)

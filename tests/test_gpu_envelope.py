@@ -1,0 +1,132 @@
+"""GPU: the default matrix path (fp32 operands as two fp16 terms) outside the benign regime of the other parity
+tests -- scaled latents, LayerNorm gains up to 10, edge-MLP weights x8, a 15-block residual stream -- against an
+fp64 evaluation of the reference formulation, and its range guard: operands of 65520 or more must raise, not
+pass silently.  Measured on MI355X (scripts/exp_envelope.py): rel-L2 2.5e-8 ... 5.9e-7 in every case below, equal
+to or below the fp32 CPU oracle's own distance from fp64; the 1e-5 bar is lost only where the guard trips
+(latents x3e4: 4.9e-5 with the flag raised)."""
+import pytest
+import torch
+
+import oracle as O
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+TOL = 1e-5
+
+
+def _problem(scale, gamma, wscale, n_layers, seed=1):
+    cfg = O.OracleConfig(process_steps=n_layers)
+    sd = O.init_state_dict(cfg, 5)
+    gen = torch.Generator().manual_seed(seed)
+    for k in list(sd):
+        if ".4.weight" in k:
+            sd[k] = gamma * (1.0 + 0.3 * torch.randn(128, generator=gen))
+        elif ".4.bias" in k:
+            sd[k] = 0.3 * gamma * torch.randn(128, generator=gen)
+        elif "edge_mlp" in k and (".0." in k or ".2." in k):
+            sd[k] = sd[k] * wscale
+    g = O.synthetic_graph(40, 30, seed=1)
+    n, ne = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
+    x, e = scale * torch.randn(n, 128, generator=gen), scale * torch.randn(ne, 128, generator=gen)
+    return cfg, sd, g, x, e
+
+
+def _fp64(sd, g, x, e, n_layers):
+    sd64 = {k: v.double() for k, v in sd.items()}
+    x64, e64, x32, e32 = x.double(), e.double(), x, e
+    with torch.no_grad():
+        for i in range(n_layers):
+            x64, e64 = O.mp_layer(sd64, i, x64, g["edge_index"], e64)
+            x32, e32 = O.mp_layer(sd, i, x32, g["edge_index"], e32)
+    return x64, e64, x32, e32
+
+
+def _gpu(sd, g, x, e, n_layers):
+    from gnn_amd.meshgraphnet import EdgeNodeMessagePassing
+    xo, eo, ei = x.to(DEV), e.to(DEV), g["edge_index"].to(DEV)
+    for i in range(n_layers):
+        m = EdgeNodeMessagePassing(128)
+        m.load_state_dict({k[len(f"processors.{i}."):]: v for k, v in sd.items() if k.startswith(f"processors.{i}.")})
+        xo, eo = m.to(DEV)(xo, ei, eo)
+    return xo, eo
+
+
+CASES = [("latents x1e-3", 1e-3, 1.0, 1.0, 1), ("latents x1e2", 1e2, 1.0, 1.0, 1), ("latents x1e3", 1e3, 1.0, 1.0, 1),
+         ("latents x1e4", 1e4, 1.0, 1.0, 1), ("LN gain 10", 1.0, 10.0, 1.0, 1), ("edge weights x8", 1.0, 1.0, 8.0, 1),
+         ("LN gain 10, edge weights x8, latents x1e2", 1e2, 10.0, 8.0, 1), ("15 blocks, LN gain 10", 1.0, 10.0, 1.0, 15),
+         ("15 blocks, LN gain 10, edge weights x8", 1.0, 10.0, 8.0, 15)]
+
+
+@pytest.mark.parametrize("name,scale,gamma,wscale,n_layers", CASES, ids=[c[0] for c in CASES])
+def test_default_matrix_path_holds_the_fp32_bar_across_its_envelope(name, scale, gamma, wscale, n_layers):
+    from gnn_amd import ops
+    assert ops.matmul_mode() == "f16x2"
+    ops.range_check(reset=True)
+    cfg, sd, g, x, e = _problem(scale, gamma, wscale, n_layers)
+    x64, e64, x32, e32 = _fp64(sd, g, x, e, n_layers)
+    xo, eo = _gpu(sd, g, x, e, n_layers)
+    rx, re, fx, fe = rel_l2(xo, x64), rel_l2(eo, e64), rel_l2(x32, x64), rel_l2(e32, e64)
+    print(f"{name}: GPU {rx:.2e}/{re:.2e}, fp32 CPU oracle {fx:.2e}/{fe:.2e} (rel-L2 of node / edge latents vs fp64)")
+    assert not ops.range_check(reset=True), "range flag raised inside the documented envelope"
+    assert rx < TOL and re < TOL
+    assert rx < 2.0 * fx + 1e-7 and re < 2.0 * fe + 1e-7      # no worse than fp32 arithmetic itself
+
+
+def test_operands_beyond_the_fp16_range_trip_the_flag_and_the_other_paths_take_over(matmul_mode):
+    """Latents of 3e4 * N(0,1): hidden activations pass 65520.  f16x2 must say so; bf16x3 and f32 have no limit."""
+    from gnn_amd import ops
+    ops.range_check(reset=True)
+    cfg, sd, g, x, e = _problem(3e4, 1.0, 1.0, 1)
+    x64, e64, _, _ = _fp64(sd, g, x, e, 1)
+    xo, eo = _gpu(sd, g, x, e, 1)
+    tripped = ops.range_check(reset=True)
+    if matmul_mode == "f16x2":
+        assert tripped
+        assert not ops.range_check(reset=True)        # the read cleared it
+    else:
+        assert not tripped
+        assert rel_l2(xo, x64) < TOL and rel_l2(eo, e64) < TOL
+
+
+def test_predict_raises_on_out_of_range_weights_and_names_the_remedy():
+    from gnn_amd import ops
+    from test_gpu_model import build_model, graph_to
+    cfg = O.OracleConfig(process_steps=2)
+    sd = O.init_state_dict(cfg, 2)
+    sd["processors.1.node_mlp.0.weight"] = sd["processors.1.node_mlp.0.weight"] * 2.0e4    # weights beyond 512
+    model = build_model(cfg, sd)
+    g = graph_to(O.synthetic_graph(12, 9, seed=3), "cuda:0")
+    with pytest.raises(RuntimeError, match="MGN_MATMUL=bf16x3"):
+        model.predict(g)
+    assert not ops.range_check(reset=True)            # raising cleared the flag: the next call starts clean
+    prev = ops.set_matmul_mode("bf16x3")
+    try:
+        out = model.predict(g)                        # same weights, no range limit, no error
+        assert bool(torch.isfinite(out).all())
+    finally:
+        ops.set_matmul_mode(prev)
+
+
+def test_predict_with_large_layernorm_gains_matches_the_oracle():
+    """Whole network (encoders, 15 blocks, decoder, integrator) with LayerNorm gains of 10 in every block."""
+    from test_gpu_model import build_model, copy_norms_frozen, graph_to
+    cfg = O.OracleConfig(process_steps=15)
+    sd = O.init_state_dict(cfg, 2)
+    gen = torch.Generator().manual_seed(7)
+    for k in list(sd):
+        if k.startswith("processors") and ".4.weight" in k:
+            sd[k] = 10.0 * (1.0 + 0.3 * torch.randn(128, generator=gen))
+    model = build_model(cfg, sd)
+    norms = O.make_norms(cfg)
+    g = O.synthetic_graph(32, 16, seed=8)
+    gg = graph_to(g, "cuda:0")
+    ref_f = O.forward(sd, cfg, norms, g)                # accumulates, then normalises
+    copy_norms_frozen(model, norms)
+    out_f = model.forward(gg)
+    ref = O.predict(sd, cfg, norms, g)
+    copy_norms_frozen(model, norms)
+    out = model.predict(gg)
+    print("LN gain 10, 15 blocks: forward rel-L2 %.3e  predict rel-L2 %.3e" % (rel_l2(out_f, ref_f), rel_l2(out, ref)))
+    assert rel_l2(out_f, ref_f) < TOL, rel_l2(out_f, ref_f)
+    assert rel_l2(out, ref) < TOL

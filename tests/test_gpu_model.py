@@ -113,7 +113,7 @@ def copy_norms_frozen(model, norms):
 
 
 @pytest.mark.parametrize("nx,ny,steps", [(32, 16, 10), (150, 100, 3), (300, 200, 2)])
-def test_predict_vs_oracle(nx, ny, steps):
+def test_predict_vs_oracle(nx, ny, steps, matmul_mode):
     """Network parity at equal normaliser statistics: encoder + processor + decoder + integrator."""
     cfg = O.OracleConfig(process_steps=steps)
     sd = O.init_state_dict(cfg, 2)

@@ -37,7 +37,7 @@ def test_mp_layer_golden():
 
 
 @pytest.mark.parametrize("nx,ny", [(32, 16), (7, 3), (1, 1), (100, 60)])
-def test_mp_layer_vs_oracle(nx, ny):
+def test_mp_layer_vs_oracle(nx, ny, matmul_mode):
     cfg = O.OracleConfig(process_steps=1)
     sd = O.init_state_dict(cfg, 5)
     # non-trivial LayerNorm affine parameters

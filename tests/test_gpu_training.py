@@ -193,7 +193,7 @@ def test_loss_grads_bending_golden():
 
 
 @pytest.mark.parametrize("nx,ny,steps,time_dim,mat", [(24, 12, 3, 1, False), (60, 40, 2, 2, True)])
-def test_loss_grads_vs_oracle(nx, ny, steps, time_dim, mat):
+def test_loss_grads_vs_oracle(nx, ny, steps, time_dim, mat, matmul_mode):
     """Every parameter gradient against the oracle's autograd at equal normaliser statistics."""
     cfg = O.OracleConfig(node_in_dim=3 + (time_dim + 1) + 5 + (2 if mat else 0), process_steps=steps, with_mat_params=mat,
                          time_dim=time_dim)
