@@ -9,7 +9,8 @@ reproduces the imported reference bit for bit, then stores the reference's outpu
 Stand-ins for wheels the reference imports but the image lacks:
   torch_scatter.scatter_add      zeros(dim_size, H).scatter_add_(0, index, src)  (torch-scatter 2.1.2)
   torch_geometric.utils.to_undirected   cat reversed edges, sort by row*N+col, unique  (PyG 2.6.1)
-  torch_geometric.{nn,data}      names only (never executed on the shipped configs)
+  torch_geometric.nn             names only (never executed on the shipped configs)
+  torch_geometric.data.Data      a dict with attribute access (the reference only constructs it and reads fields)
 """
 import os
 import sys
@@ -25,6 +26,18 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, ROOT)
 
 import oracle as O  # noqa: E402
+
+
+class Frame(dict):
+    """Attribute + item access container standing in for a PyG Data frame."""
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+    def to(self, device):
+        return self
+
+    def __deepcopy__(self, memo):
+        return Frame({k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.items()})
 
 
 def _install_shims():
@@ -50,7 +63,7 @@ def _install_shims():
 
     tgn.MessagePassing, tgn.knn_graph = object, None
     tgu.softmax, tgu.to_undirected = None, to_undirected
-    tgd.Data = object
+    tgd.Data = Frame               # core/datasetclass.py builds its frames with Data(**fields)
     tg.nn, tg.utils, tg.data = tgn, tgu, tgd
     sys.modules.update({"torch_scatter": ts, "torch_geometric": tg, "torch_geometric.nn": tgn,
                         "torch_geometric.utils": tgu, "torch_geometric.data": tgd})
@@ -61,19 +74,8 @@ sys.path.insert(0, REF)
 from core.meshgraphnet import EncodeProcessDecodeMultiScale, EdgeNodeMessagePassing  # noqa: E402
 from core.normalization import Normalizer as RefNormalizer  # noqa: E402
 from core.datasetclass import cells_to_edge_index as ref_cells_to_edge_index  # noqa: E402
+from core.datasetclass import HydrogelDataset as RefHydrogelDataset  # noqa: E402
 from core.rollout import rollout as ref_rollout  # noqa: E402
-
-
-class Frame(dict):
-    """Attribute + item access container standing in for a PyG Data frame."""
-    __getattr__ = dict.__getitem__
-    __setattr__ = dict.__setitem__
-
-    def to(self, device):
-        return self
-
-    def __deepcopy__(self, memo):
-        return Frame({k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.items()})
 
 
 def bit_equal(a, b):
@@ -294,12 +296,65 @@ def g5_rollout(T=100):
     print("g5_rollout: ok", rr["pred"].shape, ormse)
 
 
+def g6_dataset():
+    """The reference's own HydrogelDataset (core/datasetclass.py:22-119) on a small synthetic trajectory in the
+    schema of gt_gen/gt_gen/bending_gen.py:297-306: frames with and without targets, time_dim 1 and 2, noise off
+    and on (torch.manual_seed(123) right before the call; the normal draws of :77 and :84 are stored too, in call
+    order, so that the device noise kernel can be checked with the very same draws)."""
+    import tempfile
+    nx, ny, T = 8, 4, 7
+    rng = np.random.default_rng(42)
+    pos, cells = O.grid_mesh(nx, ny, lx=0.08, ly=0.01)
+    n = pos.shape[0]
+    sample = dict(mesh_coords=pos.astype(np.float32), cells=cells, node_type=O.bending_node_type(nx, ny).astype(np.float32),
+                  u_time_series=(1e-3 * rng.standard_normal((T, n, 2))).astype(np.float32),
+                  swell_time_series=np.linspace(0.30, 0.42, T).astype(np.float32), t=(0.5 * np.arange(T)).astype(np.float32),
+                  chi=np.float32(0.2), diffusivity=np.float32(7.5e-6))
+    sample["φ_time_series"] = (0.5 + 0.1 * rng.random((T, n))).astype(np.float32)
+    out = {"npz_" + k: v for k, v in sample.items()}
+    with tempfile.TemporaryDirectory() as d:
+        np.savez(os.path.join(d, "traj_a.npz"), **sample)
+        for add_targets in (True, False):
+            for time_dim in (1, 2):
+                for noise in (0.0, 0.02):
+                    if not add_targets and noise > 0:
+                        continue                      # the reference ignores noise_level without targets (:109-119)
+                    ds = RefHydrogelDataset(d, noise_level=noise, add_targets=add_targets, time_dim=time_dim)
+                    assert len(ds) == 1 and ds.get_name(0) == "traj_a"
+                    torch.manual_seed(123)
+                    frames = ds[0]
+                    tag = f"tgt{int(add_targets)}_td{time_dim}_noise{int(noise > 0)}"
+                    out[tag + "_n_frames"] = len(frames)
+                    for k in ("time", "world_pos", "phi", "swelling_phi") + (("target",) if add_targets else ()):
+                        out[f"{tag}_{k}"] = torch.stack([torch.as_tensor(fr[k]) for fr in frames]).numpy()
+                    fr0 = frames[0]
+                    for k in ("mesh_pos", "node_type", "mat_param", "cells", "edge_index"):
+                        assert all(fr[k] is fr0[k] for fr in frames)
+                    if tag == "tgt1_td1_noise0":
+                        for k in ("mesh_pos", "node_type", "mat_param", "cells", "edge_index"):
+                            out["static_" + k] = fr0[k].numpy()
+                    if noise > 0:
+                        torch.manual_seed(123)        # the same draws, in the order of :77 and :84 per frame
+                        zw, zp = [], []
+                        for fr in frames:
+                            zw.append(torch.randn(n, 2)); zp.append(torch.randn(n, 1))
+                        out[tag + "_z_world"], out[tag + "_z_phi"] = torch.stack(zw).numpy(), torch.stack(zp).numpy()
+                        out[tag + "_noise_level"] = np.float32(noise)
+    np.savez_compressed(os.path.join(HERE, "g6_dataset.npz"), **out)
+    print("g6 dataset frames ok:", sorted(k for k in out if k.endswith("_n_frames")))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:                       # regenerate only the named fixtures, e.g. `make_golden.py g6_dataset`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     g1_edges()
     g2_mp_layer()
     g3_predict_bending()
     g3b_small_general()
     g4_loss_grads()
     g5_rollout()
+    g6_dataset()
     print("all fixtures written to", HERE)

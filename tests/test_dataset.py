@@ -1,6 +1,7 @@
-"""Frames from ``.npz`` trajectories: the host dataset against the reference's frame layout
-(core/datasetclass.py:43-119, restated below field by field) and the resident trajectory against
-the host dataset.  The GPU part checks the device noise kernel bit for bit against the oracle's
+"""Frames from ``.npz`` trajectories: the host dataset and the resident trajectory against frames the
+reference's own ``HydrogelDataset`` produced (fixture g6_dataset.npz, written by tests/golden/make_golden.py
+from core/datasetclass.py:22-119 run in the build container), against the reference's frame layout
+restated field by field, and the resident trajectory against the host dataset.  The GPU part checks the device noise kernel bit for bit against the oracle's
 restatement of :75-89 with the same normal draws, and that a training step runs from a resident
 frame."""
 import numpy as np
@@ -108,3 +109,78 @@ def test_training_step_from_resident_frame(tmp_path):
     assert torch.isfinite(la) and torch.equal(la, lb)
     for (k, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
         assert torch.equal(p.grad, q.grad), k
+
+
+# --------------------------------------------------------------------------- against the reference's own frames (G6)
+G6_CONFIGS = [(True, 1, 0.0), (True, 1, 0.02), (True, 2, 0.0), (True, 2, 0.02), (False, 1, 0.0), (False, 2, 0.0)]
+
+
+def _g6(tmp_path):
+    from conftest import GOLDEN
+    d = np.load(f"{GOLDEN}/g6_dataset.npz")
+    np.savez(tmp_path / "traj_a.npz", **{k[len("npz_"):]: d[k] for k in d.files if k.startswith("npz_")})
+    return d
+
+
+def _tag(add_targets, time_dim, noise):
+    return f"tgt{int(add_targets)}_td{time_dim}_noise{int(noise > 0)}"
+
+
+@pytest.mark.parametrize("add_targets,time_dim,noise", G6_CONFIGS)
+def test_host_dataset_reproduces_reference_frames_bit_for_bit(tmp_path, add_targets, time_dim, noise):
+    """Same .npz, same seed: every field of every frame equals what core/datasetclass.py:43-119 returned, the
+    Gaussian noise of :75-89 included (same draws from torch's global generator, same arithmetic)."""
+    from gnn_amd.datasetclass import HydrogelDataset
+    d = _g6(tmp_path)
+    ds = HydrogelDataset(str(tmp_path), noise_level=noise, add_targets=add_targets, time_dim=time_dim)
+    assert len(ds) == 1 and ds.get_name(0) == "traj_a"
+    torch.manual_seed(123)
+    frames = ds[0]
+    tag = _tag(add_targets, time_dim, noise)
+    assert len(frames) == int(d[tag + "_n_frames"])
+    fields = ("time", "world_pos", "phi", "swelling_phi") + (("target",) if add_targets else ())
+    for k in fields:
+        got = torch.stack([fr[k] for fr in frames])
+        ref = torch.from_numpy(d[f"{tag}_{k}"])
+        assert got.dtype == ref.dtype and torch.equal(got, ref), k
+    assert ("target" in frames[0]) == add_targets
+    for k in ("mesh_pos", "node_type", "mat_param", "cells", "edge_index"):
+        ref = torch.from_numpy(d["static_" + k])
+        assert frames[0][k].dtype == ref.dtype and torch.equal(frames[0][k], ref), k
+        assert all(fr[k] is frames[0][k] for fr in frames)
+
+
+@pytest.mark.parametrize("time_dim", [1, 2])
+def test_resident_trajectory_reproduces_reference_frames(tmp_path, time_dim):
+    from gnn_amd.datasetclass import HydrogelDataset
+    d = _g6(tmp_path)
+    traj = HydrogelDataset(str(tmp_path), noise_level=0.0, add_targets=True, time_dim=time_dim).device_trajectory(0, "cpu")
+    tag = _tag(True, time_dim, 0.0)
+    assert len(traj) == int(d[tag + "_n_frames"])
+    for t in range(len(traj)):
+        fr = traj.frame(t)
+        for k in ("time", "world_pos", "phi", "swelling_phi", "target"):
+            assert torch.equal(fr[k], torch.as_tensor(d[f"{tag}_{k}"][t])), (t, k)
+    plain = _tag(False, time_dim, 0.0)
+    for t in (0, int(d[plain + "_n_frames"]) - 1):
+        fr = traj.frame(t, with_target=False)
+        for k in ("time", "world_pos", "phi", "swelling_phi"):
+            assert torch.equal(fr[k], torch.as_tensor(d[f"{plain}_{k}"][t])), (t, k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("time_dim", [1, 2])
+def test_device_noise_kernel_reproduces_reference_noisy_frames(tmp_path, time_dim):
+    """mgn_inject_noise fed the reference's own normal draws gives the reference's noisy frames bit for bit."""
+    from gnn_amd import ops
+    from gnn_amd.datasetclass import HydrogelDataset
+    d = _g6(tmp_path)
+    traj = HydrogelDataset(str(tmp_path), noise_level=0.02, add_targets=True, time_dim=time_dim).device_trajectory(0, "cuda:0")
+    tag = _tag(True, time_dim, 0.02)
+    level = float(d[tag + "_noise_level"])
+    for t in range(int(d[tag + "_n_frames"])):
+        zw, zp = torch.from_numpy(d[tag + "_z_world"][t]).cuda(), torch.from_numpy(d[tag + "_z_phi"][t]).cuda()
+        w, p = torch.empty_like(traj.world_pos[t]), torch.empty_like(traj.phi[t])
+        ops.inject_noise(traj.world_pos[t], traj.phi[t], traj.node_type, zw, zp, level, traj.conn_length, traj.phi_range, w, p)
+        assert torch.equal(w.cpu(), torch.from_numpy(d[f"{tag}_world_pos"][t])), t
+        assert torch.equal(p.cpu(), torch.from_numpy(d[f"{tag}_phi"][t])), t
