@@ -213,7 +213,7 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
     const int last = e1 - e0 - 1;                    // row offsets below are relative to e0 and clamped to [0, last]
     const int ntiles = last / TM + 1;
     const float* ein_g = a.e_in + (size_t)e0 * H;
-    float* eout_g = a.e_out + (size_t)e0 * H;
+    float* eout_g = a.e_out ? a.e_out + (size_t)e0 * H : nullptr;      // no edge output: never dereferenced
     const int* snd_g = a.sender + e0;
     const int* rcv_g = a.recv + e0;
     const int srow = t1 >> 5, sq = t1 & 31;          // row-major map of a role's 256 threads: rows srow + 8*it, chunk sq
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
     if (e0 >= e1) return;
     const int last = e1 - e0 - 1;                    // row offsets are relative to e0 and clamped to [0, last]
     const float* ein_g = a.e_in + (size_t)e0 * H;
-    float* eout_g = a.e_out + (size_t)e0 * H;
+    float* eout_g = a.e_out ? a.e_out + (size_t)e0 * H : nullptr;      // no edge output: never dereferenced
     const int* snd_g = a.sender + e0;
     const int* rcv_g = a.recv + e0;
     const int srow = t >> 5, sq = t & 31;            // row map: rows srow + 8*it, 16-byte chunk sq
@@ -731,11 +731,14 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         }
         return acc;
     };
-    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
+    // range guard: this kernel has no register to spare for a running maximum (all 512 are taken), so every
+    // group of splits reports its own maximum right away
     auto planes_from_acc = [&](unsigned short* tile, const f32x16& v) {
+        float m = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            hplanes_store4(tile, PL, PKH, j, 32 * w + 8 * g + 4 * h, f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, rmax);
+            hplanes_store4(tile, PL, PKH, j, 32 * w + 8 * g + 4 * h, f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, m);
+        range_report(m);
     };
     prefetch(t0);
     __syncthreads();
@@ -743,12 +746,16 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
         STAMP(0);
+        {
+            float m = 0.f;
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = srow + 8 * it;
-            *(f32x4*)(Xf + toff(row, sq, H / 4)) = px[it];
-            hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it], rmax);
-            hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it], rmax);
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
+                *(f32x4*)(Xf + toff(row, sq, H / 4)) = px[it];
+                hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it], m);
+                hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it], m);
+            }
+            range_report(m);
         }
         STAMP(1);
         __syncthreads();                                             // (1) tile staged
@@ -808,7 +815,6 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         // Xf / XAp are rewritten at the top of the next pass, after every thread's last read of them
         // (before barrier 4 resp. 2); Os / Ps / Pr are rewritten only after the next pass's barriers
     }
-    range_report(rmax);
     if constexpr (PROJ) { STAMP_FLUSH(w == 0 ? 0 : (w == 2 ? 1 : -1)) }
 }
 
@@ -998,6 +1004,7 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short Hq[HALF ? 2 * PLH : 2 * tile_floats(H / 4)];   // hidden tile
     __shared__ __attribute__((aligned(16))) float vec[H];
     __shared__ float ob[MGN_MAX_DEC_OUT], om[MGN_MAX_DEC_OUT], os[MGN_MAX_DEC_OUT];
+    __shared__ int ott[MGN_MAX_DEC_OUT], okk[MGN_MAX_DEC_OUT];     // output index -> (time step, component): no divisions in the loop
     float* X = (float*)Xp;
     float* Hs = (float*)Hq;
 
@@ -1022,6 +1029,7 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
         ob[t] = (t < n_out) ? a.b1[t] : 0.f;
         om[t] = (a.pred && t < n_out) ? a.out_mean_std[t] : 0.f;
         os[t] = (a.pred && t < n_out) ? a.out_mean_std[n_out + t] : 1.f;
+        ott[t] = t / a.out_dim; okk[t] = t % a.out_dim;
     }
     const int ntiles = (a.n_nodes + TM - 1) / TM;
     const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
@@ -1075,7 +1083,7 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
                 for (int reg = 0; reg < 16; ++reg) {
                     const int oi = (reg & 3) + 8 * (reg >> 2) + 4 * h;     // decoder output index
                     if (oi < n_out) {
-                        const int tt = oi / a.out_dim, k = oi - tt * a.out_dim;
+                        const int tt = ott[oi], k = okk[oi];
                         const float dn = (o[reg] * US + ob[oi]) * (float)(tt + 1);
                         if (a.delta_norm) a.delta_norm[((size_t)tt * a.n_nodes + n) * a.out_dim + k] = dn;
                         if (a.pred) {

@@ -87,6 +87,21 @@ def MLP(in_dim, out_dim, hidden_dims=(128, 128), activate_final=False, layer_nor
     return KernelMLP(*layers)
 
 
+def _on_graph_device(method):
+    """Runs a model method with the graph's GPU as the current device: the kernels are enqueued on the current
+    device's stream, so a model on cuda:1 called while cuda:0 is current would otherwise launch on the wrong GPU."""
+    import functools
+
+    @functools.wraps(method)
+    def wrapper(self, graph, *args, **kwargs):
+        dev = graph["mesh_pos"].device
+        if dev.type == "cuda" and dev.index is not None and dev.index != torch.cuda.current_device():
+            with torch.cuda.device(dev):
+                return method(self, graph, *args, **kwargs)
+        return method(self, graph, *args, **kwargs)
+    return wrapper
+
+
 class _Workspace:
     """Device buffers for one (device, N, E) problem size, reused across calls."""
 
@@ -292,6 +307,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         return ws, topo
 
     # ----------------------------------------------------------------- reference API
+    @_on_graph_device
     def forward(self, batch):
         """Normalised per-step deltas [time_dim, N, node_out_dim] (core/meshgraphnet.py:168-211)."""
         ws, topo = self._encode_process(batch)
@@ -302,6 +318,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         ops.raise_if_out_of_range("forward")
         return delta
 
+    @_on_graph_device
     def predict(self, graph, check_range: bool = True):
         """Next state(s) [time_dim, N, 3]: decode, de-normalise, zero the deltas of
         Dirichlet nodes, add to the current state (core/meshgraphnet.py:305-317).
@@ -346,6 +363,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             self.__dict__["_mgn_params"] = cached
         return cached
 
+    @_on_graph_device
     def loss(self, graph):
         """Masked squared error between the normalised target delta and the prediction
         (core/meshgraphnet.py:285-304): returns (total, ux, uy, phi).  The output normaliser

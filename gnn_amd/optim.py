@@ -36,6 +36,8 @@ class FusedAdam(torch.optim.Optimizer):
             dev = params[0].device
             for p in params:
                 st = self.state[p]
+                if st and torch.is_tensor(st["step"]):       # a state_dict written by torch.optim.Adam keeps the count as a tensor
+                    st["step"] = int(st["step"].item())
                 if not st:
                     if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
                         raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU")
@@ -46,7 +48,10 @@ class FusedAdam(torch.optim.Optimizer):
             step = self.state[params[0]]["step"]
             # the pointer table is rebuilt and uploaded only when an address changed (gradients are
             # usually re-allocated at the same addresses step after step)
-            key = tuple(p.grad.data_ptr() for p in params) + tuple(p.data_ptr() for p in params)
+            # (load_state_dict / a replaced state entry installs new moment tensors: their addresses are part of the key)
+            key = (tuple(p.grad.data_ptr() for p in params) + tuple(p.data_ptr() for p in params)
+                   + tuple(self.state[p]["exp_avg"].data_ptr() for p in params)
+                   + tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in params))
             cache = self.__dict__.setdefault("_tables", {})
             hit = cache.get(gi)
             if hit is None or hit[0] != key:

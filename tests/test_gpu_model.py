@@ -66,6 +66,17 @@ def test_predict_bending_golden():
         assert np.array_equal(g[k].numpy(), d[f"g_{k}"]), k
     gg = graph_to(g, DEV)
     fwd = model.forward(gg)
+    # latents of that first call against the reference's (row sums): the processor output still sits in the
+    # workspace, the node encoder is re-run alone on the workspace's raw features at the statistics just used
+    from gnn_amd import ops
+    ws = model.__dict__["_ws"]
+    def rowsum_close(x, ref_rowsum):          # row sums cancel: bound the difference by the rows' absolute mass
+        bound = TOL * float(x.double().abs().sum(1).max())
+        return float((x.double().sum(1).cpu() - ref_rowsum).abs().max()) <= bound
+    assert rowsum_close(ws.x, torch.from_numpy(d["x_proc_rowsum"]))
+    x_enc = torch.empty(561, 128, device=DEV)
+    ops.encode(ws.node_feat, model.node_features_normalizer.stats_for(None, accumulate=False), model.node_encoder.weights(), x_enc)
+    assert rowsum_close(x_enc, torch.from_numpy(d["x_enc_rowsum"]))
     prd = model.predict(gg)
     assert fwd.shape == (1, 561, 3) and prd.shape == (1, 561, 3)
     assert rel_l2(fwd, torch.from_numpy(d["forward"])) < TOL, rel_l2(fwd, torch.from_numpy(d["forward"]))

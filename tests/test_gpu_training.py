@@ -260,6 +260,42 @@ def test_fused_adam_matches_torch_adam():
     assert all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd["state"].values())
 
 
+def test_fused_adam_resumes_from_a_loaded_state():
+    """step, save, step, load, step: after load_state_dict the moments are new tensors; the cached pointer table
+    must follow them (and not keep updating the old, freed ones).  torch.optim.Adam walks the same sequence."""
+    import copy
+    from gnn_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(1)
+    shapes = [(128, 128), (128,), (20000,)]
+    ref = [torch.randn(*sh, generator=gen).requires_grad_(True) for sh in shapes]
+    mine = [p.detach().clone().to(DEV).requires_grad_(True) for p in ref]
+    o_ref, o_mine = torch.optim.Adam(ref, lr=1e-2, weight_decay=1e-5), FusedAdam(mine, lr=1e-2, weight_decay=1e-5)
+
+    def step():
+        for p, q in zip(ref, mine):
+            g = torch.randn(*p.shape, generator=gen)
+            p.grad, q.grad = g.clone(), g.to(DEV)
+        o_ref.step(); o_mine.step()
+
+    step()
+    saved_ref, saved_mine = copy.deepcopy(o_ref.state_dict()), copy.deepcopy(o_mine.state_dict())
+    w_ref, w_mine = [p.detach().clone() for p in ref], [q.detach().clone() for q in mine]
+    step(); step()
+    with torch.no_grad():                        # roll back: weights and optimizer state of the checkpoint
+        for p, w in zip(ref, w_ref):
+            p.copy_(w)
+        for q, w in zip(mine, w_mine):
+            q.copy_(w)
+    o_ref.load_state_dict(saved_ref); o_mine.load_state_dict(saved_mine)
+    junk = [torch.full((1 << 20,), float("nan"), device=DEV) for _ in range(4)]      # reuse whatever memory was freed
+    step(); step()
+    del junk
+    for p, q in zip(ref, mine):
+        assert rel_l2(q.detach(), p.detach()) < 1e-6, rel_l2(q.detach(), p.detach())
+    st = o_mine.state[mine[0]]
+    assert st["step"] == 3 and bool(torch.isfinite(st["exp_avg"]).all())
+
+
 def test_fused_edge_backward_matches_unfused():
     """The training step that recomputes the edge MLP's hidden activations in the backward
     (mgn_train_edge_bwd) against the step that keeps them: same loss, gradients equal to 2e-6
