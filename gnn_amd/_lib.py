@@ -37,6 +37,9 @@ SIGNATURES = {
     "mgn_receiver_csr_dev": (C.c_int, [_P, _P, _I64, _I64, _P, _I64, _P, _P, _P, _P, _P]),
     "mgn_mp_project": (C.c_int, [_P, _P, _P, _P, _P, _I64, _P]),
     "mgn_mp_edge": (C.c_int, [_P, _P, _P, _P, _P, _P, _MLP, _P, _P, _I64, _I64, _P]),
+    "mgn_mp_edge_weighted": (C.c_int, [_P, _P, _P, _P, _P, _P, _MLP, _P, _P, _P, _I64, _I64, _P]),
+    "mgn_edge_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mgn_decode_cat": (C.c_int, [_P, _P, _MLP, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_mp_node": (C.c_int, [_P, _P, _P, _MLP, _P, _I64, _P]),
     "mgn_mp_node_project": (C.c_int, [_P, _P, _P, _MLP, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_node_features": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),

@@ -46,8 +46,10 @@ struct EdgeArgs {
     const float* w0; const float* w1; const float* b1; const float* ln_w; const float* ln_b;
     float* e_out; float* aggr;
     int n_edges; int n_nodes;
+    const float* ew;                 // ATT kernels: per-edge weight of the message in the receiver's sum (attention)
 };
 
+template <bool ATT>
 __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) float X[2][tile_floats(H / 4)];   // staged e_in tile, double buffered
     __shared__ __attribute__((aligned(16))) float Hs[tile_floats(H / 4)];     // hidden tile, then the edge output
@@ -156,7 +158,10 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
                 if (r0 < nvalid) {
                     float v[8]; int id[9];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) { v[k] = col[(r0 + k) * (H + 4)]; id[k] = rr[r0 + k]; }
+                    for (int k = 0; k < 8; ++k) {
+                        v[k] = col[(r0 + k) * (H + 4)]; id[k] = rr[r0 + k];
+                        if constexpr (ATT) v[k] *= a.ew[min(base + r0 + k, e1 - 1)];
+                    }
                     id[8] = rr[r0 + 8];
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -186,6 +191,7 @@ constexpr int NT3 = 512;
 //
 // Wave w of a role owns output features [32w, 32w+32) of its Linear with the three bf16 weight
 // planes in registers (96 VGPRs).
+template <bool ATT>
 __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short Xp[3 * PLANE];      // staged e_in tile, 3 planes
     __shared__ __attribute__((aligned(16))) unsigned short Hp[2][3 * PLANE];   // hidden tile, 3 planes, double buffered
@@ -327,7 +333,10 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
                 // receiver-segmented sum: thread (column sc, group sg) scans rows 16sg .. 16sg+15 in
                 // order; xr[r] = sum of the rows since the last segment end before r
 #pragma unroll
-                for (int r = 0; r < 16; ++r) xr[r] = Es[(16 * sg + r) * (H + 4) + sc];
+                for (int r = 0; r < 16; ++r) {
+                    xr[r] = Es[(16 * sg + r) * (H + 4) + sc];
+                    if constexpr (ATT) xr[r] *= a.ew[e0 + min(relk + 16 * sg + r, last)];
+                }
                 part = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -392,6 +401,7 @@ constexpr int PLH = TM * PKH;         // halves per fp16 plane of a 32-row tile
 //         halves chained through LDS: barrier S); residual (rows kept in registers) + coalesced store;
 //         segment sums -> aggr                                                         barrier E
 // All global stores of a tile come after its last wait for a load, so no wait drains the store queue.
+template <bool ATT>
 __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short Xp[2][2 * PLH];     // e_in tile, 2 fp16 planes, double buffered
     __shared__ __attribute__((aligned(16))) unsigned short Hp[2 * PLH];        // hidden tile, 2 fp16 planes; then Os
@@ -513,7 +523,10 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
         const unsigned gmask = (mask >> (16 * sg)) & 0xFFFFu;
         float xr[16], part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xr[r] = Os[(16 * sg + r) * (H + 4) + sc];
+        for (int r = 0; r < 16; ++r) {
+            xr[r] = Os[(16 * sg + r) * (H + 4) + sc];
+            if constexpr (ATT) xr[r] *= a.ew[e0 + min(rel + 16 * sg + r, last)];      // wave-uniform address
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             part += xr[r];
@@ -1013,18 +1026,19 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
     constexpr float BS = HALF ? W_SCALE : 1.0f, US = HALF ? W_UNSCALE : 1.0f;
     f32x4 wa[HALF ? 1 : 16], wb[HALF ? 1 : 16];
     WPlanesH<HALF ? 8 : 1> ha, hb;
+    const bool hidden_in = a.w0 == nullptr;          // x already holds the hidden activations (first Linear done by the caller)
     if constexpr (HALF) {
-        load_wplanes_h<8>(ha, a.w0, H, 0, 32 * w + j, h);
+        if (!hidden_in) load_wplanes_h<8>(ha, a.w0, H, 0, 32 * w + j, h);
         load_wplanes_h<8>(hb, a.w1, H, 0, min(j, n_out - 1), h);
         if (!(w == 0 && j < n_out)) {                // rows >= n_out read as zero
 #pragma unroll
             for (int c = 0; c < 8; ++c) { hb.p[0][c] = u32x4{0, 0, 0, 0}; hb.p[1][c] = u32x4{0, 0, 0, 0}; }
         }
     } else {
-        load_wfrag<16>(wa, a.w0, H, 0, 32 * w + j, h);
+        if (!hidden_in) load_wfrag<16>(wa, a.w0, H, 0, 32 * w + j, h);
         load_wfrag<16>(wb, a.w1, H, 0, min(j, n_out - 1), h, w == 0 && j < n_out);   // rows >= n_out read as zero
     }
-    if (t < H) vec[t] = a.b0[t] * BS;
+    if (t < H) vec[t] = hidden_in ? 0.f : a.b0[t] * BS;
     if (t < MGN_MAX_DEC_OUT) {
         ob[t] = (t < n_out) ? a.b1[t] : 0.f;
         om[t] = (a.pred && t < n_out) ? a.out_mean_std[t] : 0.f;
@@ -1048,8 +1062,8 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int row = srow + 8 * it;
-            if constexpr (HALF) hplanes_store4(Xp, PLH, PKH, row, 4 * sq, pre[it], rmax);
-            else *(f32x4*)(X + toff(row, sq, H / 4)) = pre[it];
+            if constexpr (HALF) hplanes_store4(hidden_in ? Hq : Xp, PLH, PKH, row, 4 * sq, pre[it], rmax);
+            else *(f32x4*)((hidden_in ? Hs : X) + toff(row, sq, H / 4)) = pre[it];
         }
         __syncthreads();
         if (tile + 1 < t1) {
@@ -1058,7 +1072,9 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
                 pre[it] = *(const f32x4*)(a.x + (size_t)min(base + TM + srow + 8 * it, a.n_nodes - 1) * H + 4 * sq);
         }
         f32x16 acc = acc_from_vec(vec, w, h);
-        if constexpr (HALF) {
+        if (hidden_in) {
+            // nothing to do: the staged rows are the hidden tile
+        } else if constexpr (HALF) {
             acc = wave_gemm_h<0, 8, 8>(Xp, PLH, PKH, 0, ha, j, h, acc);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
@@ -1129,6 +1145,33 @@ __global__ void edge_features_kernel(const float* __restrict__ world_pos, const 
         f[0] = mx; f[1] = my; f[2] = sqrtf(mx * mx + my * my);
         f[3] = wx; f[4] = wy; f[5] = sqrtf(wx * wx + wy * wy);
         f[6] = phi[s] - phi[r];
+    }
+}
+
+// ======================================================================== attention weights of the messages
+// core/meshgraphnet.py:100-107: alpha_e = leaky_relu(<A[s_e], A[r_e]>) with A = attn_lin(x); the message of edge e
+// enters its receiver's sum with weight alpha_e / max(sum of alpha over the receiver's in-edges, 1e-6).
+// 32 lanes per edge (16 bytes of each row per lane); then one thread per receiver adds its alphas in CSR order.
+__global__ __launch_bounds__(NT) void edge_alpha_kernel(const float* __restrict__ A, const int* __restrict__ sender,
+                                                        const int* __restrict__ recv, float* __restrict__ alpha, int n_edges) {
+    const int l = threadIdx.x & 31;
+    for (long long e = ((long long)blockIdx.x * NT + threadIdx.x) >> 5; e < n_edges; e += ((long long)gridDim.x * NT) >> 5) {
+        const f32x4 u = *(const f32x4*)(A + (size_t)sender[e] * H + 4 * l), v = *(const f32x4*)(A + (size_t)recv[e] * H + 4 * l);
+        float d = (u[0] * v[0] + u[1] * v[1]) + (u[2] * v[2] + u[3] * v[3]);
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) d += __shfl_xor(d, m, 32);
+        if (l == 0) alpha[e] = d > 0.f ? d : 0.01f * d;
+    }
+}
+
+__global__ void edge_alpha_normalize_kernel(const int* __restrict__ rowptr, const float* __restrict__ alpha,
+                                            float* __restrict__ weight, int n_nodes) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += gridDim.x * blockDim.x) {
+        const int b = rowptr[n], e = rowptr[n + 1];
+        float s = 0.f;
+        for (int k = b; k < e; ++k) s += alpha[k];
+        const float d = fmaxf(s, 1e-6f);
+        for (int k = b; k < e; ++k) weight[k] = alpha[k] / d;
     }
 }
 
@@ -1290,27 +1333,62 @@ extern "C" int mgn_mp_project(const float* x, const float* edge_w0, const float*
     return check_launch("mgn_mp_project");
 }
 
+static int launch_edge(const float* e_in, const float* ps, const float* pr, const int32_t* rowptr,
+                       const int32_t* csr_sender, const int32_t* csr_recv, const mgn_mlp* m, const float* edge_weight,
+                       float* e_out, float* aggr, int64_t n_edges, int64_t n_nodes, void* stream, const char* name) {
+    MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31) && n_nodes >= 0 && n_nodes < (1ll << 31), name);
+    if (n_edges == 0) return 0;
+    MGN_REQUIRE(e_in && ps && pr && rowptr && csr_sender && csr_recv && aggr && mlp_ok(m, true), name);
+    // node rows are addressed with 32-bit element offsets
+    MGN_REQUIRE(n_nodes * (int64_t)H < (1ll << 31), name);
+    EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
+               e_out, aggr, (int)n_edges, (int)n_nodes, edge_weight};
+    const hipStream_t st = (hipStream_t)stream;
+    if (matmul_mode() == 2) {
+        const int g = grid_for((n_edges + TM - 1) / TM, 2);
+        if (edge_weight) hipLaunchKernelGGL((mp_edge_h4_kernel<true>), dim3(g), dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL((mp_edge_h4_kernel<false>), dim3(g), dim3(NT), 0, st, a);
+    } else if (matmul_mode() == 1) {
+        const int g = grid_for((n_edges + TM - 1) / TM, 1);
+        if (edge_weight) hipLaunchKernelGGL((mp_edge3_kernel<true>), dim3(g), dim3(NT3), 0, st, a);
+        else hipLaunchKernelGGL((mp_edge3_kernel<false>), dim3(g), dim3(NT3), 0, st, a);
+    } else {
+        const int g = grid_for((n_edges + TM - 1) / TM, 2);
+        if (edge_weight) hipLaunchKernelGGL((mp_edge_kernel<true>), dim3(g), dim3(NT), 0, st, a);
+        else hipLaunchKernelGGL((mp_edge_kernel<false>), dim3(g), dim3(NT), 0, st, a);
+    }
+    return check_launch(name);
+}
+
 extern "C" int mgn_mp_edge(const float* e_in, const float* ps, const float* pr, const int32_t* rowptr,
                            const int32_t* csr_sender, const int32_t* csr_recv, const mgn_mlp* m, float* e_out,
                            float* aggr, int64_t n_edges, int64_t n_nodes, void* stream) {
-    MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31) && n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_mp_edge");
-    if (n_edges == 0) return 0;
-    MGN_REQUIRE(e_in && ps && pr && rowptr && csr_sender && csr_recv && aggr && mlp_ok(m, true), "mgn_mp_edge");
-    // node rows are addressed with 32-bit element offsets
-    MGN_REQUIRE(n_nodes * (int64_t)H < (1ll << 31), "mgn_mp_edge");
-    EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
-               e_out, aggr, (int)n_edges, (int)n_nodes};
-    if (matmul_mode() == 2) {
-        const int g = grid_for((n_edges + TM - 1) / TM, 2);
-        hipLaunchKernelGGL(mp_edge_h4_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
-    } else if (matmul_mode() == 1) {
-        const int g = grid_for((n_edges + TM - 1) / TM, 1);
-        hipLaunchKernelGGL(mp_edge3_kernel, dim3(g), dim3(NT3), 0, (hipStream_t)stream, a);
-    } else {
-        const int g = grid_for((n_edges + TM - 1) / TM, 2);
-        hipLaunchKernelGGL(mp_edge_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
-    }
-    return check_launch("mgn_mp_edge");
+    return launch_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, m, nullptr, e_out, aggr, n_edges, n_nodes, stream,
+                       "mgn_mp_edge");
+}
+
+extern "C" int mgn_mp_edge_weighted(const float* e_in, const float* ps, const float* pr, const int32_t* rowptr,
+                                    const int32_t* csr_sender, const int32_t* csr_recv, const mgn_mlp* m,
+                                    const float* edge_weight, float* e_out, float* aggr, int64_t n_edges,
+                                    int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(edge_weight || n_edges == 0, "mgn_mp_edge_weighted");
+    return launch_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, m, edge_weight, e_out, aggr, n_edges, n_nodes, stream,
+                       "mgn_mp_edge_weighted");
+}
+
+extern "C" int mgn_edge_attention(const float* a_proj, const int32_t* rowptr, const int32_t* csr_sender,
+                                  const int32_t* csr_recv, float* alpha, float* edge_weight, int64_t n_edges,
+                                  int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31) && n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_edge_attention");
+    if (n_edges == 0 || n_nodes == 0) return 0;
+    MGN_REQUIRE(a_proj && rowptr && csr_sender && csr_recv && alpha && edge_weight, "mgn_edge_attention");
+    const int g1 = (int)std::min<int64_t>((n_edges * 32 + NT - 1) / NT, 16384);
+    hipLaunchKernelGGL(edge_alpha_kernel, dim3(g1), dim3(NT), 0, (hipStream_t)stream, a_proj, csr_sender, csr_recv, alpha,
+                       (int)n_edges);
+    const int g2 = (int)std::min<int64_t>((n_nodes + NT - 1) / NT, 16384);
+    hipLaunchKernelGGL(edge_alpha_normalize_kernel, dim3(g2), dim3(NT), 0, (hipStream_t)stream, rowptr, alpha, edge_weight,
+                       (int)n_nodes);
+    return check_launch("mgn_edge_attention");
 }
 
 static int launch_node(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* m,
@@ -1504,6 +1582,27 @@ extern "C" int mgn_decode(const float* x, const mgn_mlp* dec, int32_t time_dim, 
     if (matmul_mode() == 2) hipLaunchKernelGGL((decode_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((decode_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     return check_launch("mgn_decode");
+}
+
+extern "C" int mgn_decode_cat(const float* x, const float* x2, const mgn_mlp* dec, int32_t time_dim, int32_t out_dim,
+                              float* hidden_ws, float* delta_norm, const float* out_mean_std, const float* world_pos,
+                              const float* phi, const float* node_type, float* pred, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && time_dim > 0 && out_dim > 0 &&
+                time_dim * out_dim <= MGN_MAX_DEC_OUT, "mgn_decode_cat");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(x && x2 && hidden_ws && mlp_ok(dec, false) && (delta_norm || pred), "mgn_decode_cat");
+    MGN_REQUIRE(!pred || (out_dim == 3 && out_mean_std && world_pos && phi && node_type), "mgn_decode_cat");
+    // first Linear over cat[x, x2] with its ReLU (the two-block Linear of the training kernels), then the decoder
+    // kernel entered at its hidden tile
+    const int rc = mgn_train_linear_fwd(x, x2, dec->w0, 2 * H, 0, H, dec->b0, nullptr, nullptr, nullptr, nullptr, 1,
+                                        hidden_ws, n_nodes, stream);
+    if (rc) return rc;
+    DecArgs a{hidden_ws, nullptr, nullptr, dec->w1, dec->b1, delta_norm, out_mean_std, world_pos, phi, node_type,
+              pred, (int)n_nodes, (int)time_dim, (int)out_dim};
+    const int g = grid_for((n_nodes + TM - 1) / TM, 2);
+    if (matmul_mode() == 2) hipLaunchKernelGGL((decode_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((decode_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_decode_cat");
 }
 
 extern "C" int mgn_normalize(const float* x, const float* mean_std, float* out, int64_t rows, int32_t n_feat,

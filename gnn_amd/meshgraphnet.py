@@ -5,8 +5,9 @@ Public surface and checkpoint layout follow ``core/meshgraphnet.py`` of the refe
 ``EncodeProcessDecodeMultiScale`` (:122-332) with ``forward`` / ``loss`` / ``predict`` /
 ``save_model`` / ``load_model``.  Parameters sit in the same ``nn.Sequential`` slots, so
 ``state_dict`` has the reference's 136 keys and a seeded construction draws the same
-weights.  All arithmetic runs in libmgn_hip.so; there is no PyTorch or CPU fallback, and
-options the kernels do not cover (attention, the coarse multiscale branch) raise.
+weights.  All arithmetic runs in libmgn_hip.so; there is no PyTorch or CPU fallback.  The attention option
+(:60-61, :100-108) and the coarse multiscale branch (:148-156, :179-194, :237-283), off in every shipped config,
+run in ``forward`` / ``predict`` / ``rollout``; ``loss`` covers the shipped configuration only and raises for them.
 """
 from __future__ import annotations
 
@@ -126,11 +127,10 @@ class EdgeNodeMessagePassing(nn.Module):
         super().__init__()
         if hidden_dim != H:
             raise NotImplementedError(f"EdgeNodeMessagePassing: hidden_dim must be {H} for the HIP kernels")
-        if attention:
-            raise NotImplementedError("EdgeNodeMessagePassing: attention=True has no HIP kernel "
-                                      "(every shipped config of the reference sets attention: false)")
         self.hidden_dim = hidden_dim
         self.attention = attention
+        if self.attention:                  # created before the two MLPs, as the reference does (core/meshgraphnet.py:60-61)
+            self.attn_lin = nn.Linear(hidden_dim, hidden_dim)
         self.edge_mlp = KernelMLP(nn.Linear(hidden_dim * 3, hidden_dim), nn.ReLU(),
                                   nn.Linear(hidden_dim, hidden_dim), nn.ReLU(), nn.LayerNorm(hidden_dim))
         self.node_mlp = KernelMLP(nn.Linear(hidden_dim * 2, hidden_dim), nn.ReLU(),
@@ -150,10 +150,24 @@ class EdgeNodeMessagePassing(nn.Module):
         ew, nw = self.edge_mlp.weights(), self.node_mlp.weights()
         n = x.shape[0] if halo is None else halo.num_owned
         e_out = e_csr if store_edges else None
+        wts = None
+        if self.attention:
+            # message weights from the OLD node latents (core/meshgraphnet.py:101-107): a = attn_lin(x), then per edge
+            # leaky_relu(<a[s], a[r]>) over its sum per receiver
+            if halo is not None:
+                raise NotImplementedError("attention is not combined with mesh partitioning")
+            buf = self.__dict__.get("_att")
+            if buf is None or buf[0].shape[0] != x.shape[0] or buf[1].shape[0] != e_csr.shape[0] or buf[0].device != x.device:
+                buf = (torch.empty_like(x), torch.empty(e_csr.shape[0], dtype=torch.float32, device=x.device),
+                       torch.empty(e_csr.shape[0], dtype=torch.float32, device=x.device))
+                self.__dict__["_att"] = buf
+            a_proj, alpha, wts = buf
+            ops.train_linear_fwd(x, self.attn_lin.weight.data, 0, a_proj, bias=self.attn_lin.bias.data)
+            ops.edge_attention(a_proj, topo.rowptr, topo.sender, topo.recv, alpha, wts)
         if halo is None and not ops.timing_enabled():       # the common path, without the timing contexts
             if not projected:
                 ops.mp_project(x, self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps, pr)
-            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr)
+            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, edge_weight=wts)
             if next_block is None:
                 ops.mp_node(x, aggr, topo.rowptr, nw, x)
             else:
@@ -165,7 +179,7 @@ class EdgeNodeMessagePassing(nn.Module):
                 ops.mp_project(x[:n], self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps[:n], pr[:n])
         if halo is None:
             with ops.timed("mp_edge"):
-                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr)
+                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, edge_weight=wts)
         else:
             # the receivers whose in-edges all come from owned senders are updated while the halo
             # rows of `ps` are in flight; the rest follows once they have arrived
@@ -216,12 +230,6 @@ class EncodeProcessDecodeMultiScale(nn.Module):
                  time_dim=1,
                  device="cpu"):
         super().__init__()
-        if sample_ratio > 0:
-            raise NotImplementedError(
-                "EncodeProcessDecodeMultiScale: sample_ratio > 0 (coarse multiscale branch, core/meshgraphnet.py:"
-                "148-156, :179-194) has no HIP implementation; every shipped config uses sample_ratio: 0.0")
-        if attention:
-            raise NotImplementedError("EncodeProcessDecodeMultiScale: attention=True has no HIP implementation")
         if hidden_size != H:
             raise NotImplementedError(f"EncodeProcessDecodeMultiScale: hidden_size must be {H}")
         if edge_in_dim != 7:
@@ -236,7 +244,18 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         self.process_steps = process_steps
         self.coarse_process_steps = coarse_process_steps
         self.processors = nn.ModuleList([EdgeNodeMessagePassing(hidden_size, attention) for _ in range(process_steps)])
-        self.node_decoder = MLP(hidden_size, node_out_dim * time_dim, hidden_dims=(hidden_size,), layer_norm=False)
+        if sample_ratio > 0:                # coarse branch, modules in the reference's order (core/meshgraphnet.py:148-156)
+            self.coarse_edge_encoder = MLP(edge_in_dim, hidden_size, hidden_dims=(hidden_size,), layer_norm=True)
+            self.coarse_edge_features_normalizer = Normalizer(1, edge_in_dim, "edge_features_normalizer", device)
+            self.coarse_processors = nn.ModuleList([EdgeNodeMessagePassing(hidden_size, attention)
+                                                    for _ in range(coarse_process_steps)])
+            self.node_decoder = nn.Sequential(nn.Linear(2 * hidden_size, hidden_size), nn.ReLU(),
+                                              nn.Linear(hidden_size, node_out_dim * time_dim))
+        else:
+            self.node_decoder = MLP(hidden_size, node_out_dim * time_dim, hidden_dims=(hidden_size,), layer_norm=False)
+        # first sample of the coarse graph's farthest-point sampling: None = drawn anew on every call, as the
+        # reference does (core/meshgraphnet.py:248); an int pins it (and lets the coarse graph be cached)
+        self.__dict__["coarse_start"] = None
         self.device = device
         self.node_features_normalizer = Normalizer(1, node_in_dim, "node_features_normalizer", device)
         self.edge_features_normalizer = Normalizer(1, edge_in_dim, "edge_features_normalizer", device)
@@ -264,6 +283,41 @@ class EncodeProcessDecodeMultiScale(nn.Module):
     @staticmethod
     def _f32(t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(torch.float32).contiguous()
+
+    def _coarse_graph(self, mesh_pos):
+        from .coarse import CoarseGraph
+        start = self.__dict__.get("coarse_start")
+        n = mesh_pos.shape[0]
+        if start is None:                         # the reference's draw (core/meshgraphnet.py:248), same call on the same device
+            return CoarseGraph(mesh_pos, self.sample_ratio, int(torch.randint(0, n, (1,), device=mesh_pos.device)), mesh_pos.device)
+        key = (mesh_pos.data_ptr(), mesh_pos._version, n, str(mesh_pos.device), int(start), float(self.sample_ratio))
+        hit = self.__dict__.get("_coarse")
+        if hit is None or hit[0] != key:
+            hit = (key, CoarseGraph(mesh_pos, self.sample_ratio, int(start), mesh_pos.device), mesh_pos)
+            self.__dict__["_coarse"] = hit
+        return hit[1]
+
+    def _coarse_workspace(self, device, cg):
+        n, nc, ec = self.__dict__["_ws"].x.shape[0], cg.num_nodes, cg.topology.num_edges
+        cw = self.__dict__.get("_cws")
+        if cw is None or cw.key != (str(device), n, nc, ec):
+            f32 = dict(dtype=torch.float32, device=device)
+            cw = type("CoarseWorkspace", (), {})()
+            cw.key = (str(device), n, nc, ec)
+            cw.x, cw.ps, cw.pr, cw.aggr = (torch.empty(nc, H, **f32) for _ in range(4))
+            cw.e, cw.edge_feat = torch.empty(ec, H, **f32), torch.empty(ec, 7, **f32)
+            cw.map_back, cw.hidden = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
+            self.__dict__["_cws"] = cw
+        return cw
+
+    def _decode(self, ws, n, **kw):
+        """Decoder (+ integrator): over the fine latents, or over cat[fine, coarse mapped back] in the multiscale model."""
+        if self.sample_ratio > 0:
+            cw, d = self.__dict__["_cws"], self.node_decoder
+            ops.decode_cat(ws.x[:n], cw.map_back, d[0].weight.data, d[0].bias.data, d[2].weight.data, d[2].bias.data,
+                           self.time_dim, self.node_out_dim, cw.hidden, **kw)
+        else:
+            ops.decode(ws.x[:n], self.node_decoder.weights(), self.time_dim, self.node_out_dim, **kw)
 
     def _encode_process(self, graph):
         """Features -> normalise (accumulating) -> encode -> process.  Returns the workspace
@@ -299,11 +353,29 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         ops.encode(ws.node_feat[:n_own], ms_n, self.node_encoder.weights(), ws.x[:n_own])
         ms_e = self.edge_features_normalizer.stats_for(ws.edge_feat, True, hook_e)
         ops.encode(ws.edge_feat, ms_e, self.edge_encoder.weights(), ws.e)
+        cg = cw = None
+        if self.sample_ratio > 0:                 # core/meshgraphnet.py:179-182
+            if halo is not None:
+                raise NotImplementedError("the coarse multiscale branch is not combined with mesh partitioning")
+            cg = self._coarse_graph(graph["mesh_pos"])
+            cw = self._coarse_workspace(dev, cg)
+            ops.edge_features(world, mesh, phi, cg.sender_orig, cg.recv_orig, cw.edge_feat)
+            ms_c = self.coarse_edge_features_normalizer.stats_for(cw.edge_feat, True)
+            ops.encode(cw.edge_feat, ms_c, self.coarse_edge_encoder.weights(), cw.e)
+            ops.gather_rows(ws.x, cg.first, cw.x)          # encoder output of the sampled nodes (:182)
         blocks = list(self.processors)
         for i, proc in enumerate(blocks):
             last = i + 1 == len(blocks)           # nothing reads the edge latents after the last block
             proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr, halo, projected=i > 0,
                           next_block=None if last else blocks[i + 1], store_edges=not last)
+        if cg is not None:                        # :187-194
+            cblocks = list(self.coarse_processors)
+            for i, proc in enumerate(cblocks):
+                last = i + 1 == len(cblocks)
+                proc.step_csr(cw.x, cw.e, cg.topology, cw.ps, cw.pr, cw.aggr, None, projected=i > 0,
+                              next_block=None if last else cblocks[i + 1], store_edges=not last)
+            cw.map_back.zero_()
+            ops.scatter_rows(cw.x, cg.first, cw.map_back)
         return ws, topo
 
     # ----------------------------------------------------------------- reference API
@@ -314,7 +386,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         halo = self.__dict__.get("halo")
         n = halo.num_owned if halo is not None else topo.num_nodes
         delta = torch.empty(self.time_dim, n, self.node_out_dim, dtype=torch.float32, device=ws.x.device)
-        ops.decode(ws.x[:n], self.node_decoder.weights(), self.time_dim, self.node_out_dim, delta_norm=delta)
+        self._decode(ws, n, delta_norm=delta)
         ops.raise_if_out_of_range("forward")
         return delta
 
@@ -334,9 +406,8 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             n = halo.num_owned if halo is not None else topo.num_nodes
             ms_o = self.output_normalizer.stats_for(None, accumulate=False)
             pred = torch.empty(self.time_dim, n, 3, dtype=torch.float32, device=ws.x.device)
-            ops.decode(ws.x[:n], self.node_decoder.weights(), self.time_dim, 3, out_mean_std=ms_o,
-                       world_pos=self._f32(graph["world_pos"])[:n], phi=self._f32(graph["phi"])[:n],
-                       node_type=self._f32(graph["node_type"])[:n], pred=pred)
+            self._decode(ws, n, out_mean_std=ms_o, world_pos=self._f32(graph["world_pos"])[:n],
+                         phi=self._f32(graph["phi"])[:n], node_type=self._f32(graph["node_type"])[:n], pred=pred)
         if check_range:
             ops.raise_if_out_of_range("predict")
         return pred
@@ -371,6 +442,10 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         of the HIP training kernels, so ``loss.backward()`` fills ``.grad`` of every parameter
         as run_train_multiscale.py:139-141 expects."""
         from . import training
+        if self.attention or self.sample_ratio > 0:
+            raise NotImplementedError("loss(): the training kernels cover the configuration every shipped config uses "
+                                      "(attention off, sample_ratio 0); the attention and multiscale options run in "
+                                      "forward() / predict() / rollout() only")
         tgt = self._normalized_target(graph)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()[1]):
             comps = training.loss_components(self, graph, tgt)
@@ -385,6 +460,8 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         torch.save(self.output_normalizer, os.path.join(path, "output_normalizer.pth"))
         torch.save(self.node_features_normalizer, os.path.join(path, "node_features_normalizer.pth"))
         torch.save(self.edge_features_normalizer, os.path.join(path, "edge_features_normalizer.pth"))
+        if self.sample_ratio > 0:
+            torch.save(self.coarse_edge_features_normalizer, os.path.join(path, "coarse_edge_features_normalizer.pth"))
 
     def load_model(self, path):
         """Loads the reference's checkpoint directory (core/meshgraphnet.py:326-332).  The
@@ -395,6 +472,8 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         self.output_normalizer = load_normalizer(os.path.join(path, "output_normalizer.pth"), dev)
         self.node_features_normalizer = load_normalizer(os.path.join(path, "node_features_normalizer.pth"), dev)
         self.edge_features_normalizer = load_normalizer(os.path.join(path, "edge_features_normalizer.pth"), dev)
+        if self.sample_ratio > 0:
+            self.coarse_edge_features_normalizer = load_normalizer(os.path.join(path, "coarse_edge_features_normalizer.pth"), dev)
 
     def _apply(self, fn, *args, **kwargs):
         """``.to(device)`` also moves the normaliser statistics, which the reference keeps
@@ -404,9 +483,14 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             dev = next(self.parameters()).device
         except StopIteration:
             return self
-        for nrm in (self.node_features_normalizer, self.edge_features_normalizer, self.output_normalizer):
+        norms = [self.node_features_normalizer, self.edge_features_normalizer, self.output_normalizer]
+        if self.sample_ratio > 0:
+            norms.append(self.coarse_edge_features_normalizer)
+        for nrm in norms:
             if nrm._acc_sum.device != dev:
                 nrm.to_device(dev)
         self.__dict__["_ws"] = None
+        self.__dict__["_cws"] = None
+        self.__dict__["_coarse"] = None
         self.__dict__["_mgn_params"] = None
         return self

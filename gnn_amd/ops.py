@@ -214,9 +214,10 @@ def mp_project(x, w0, b0, ps, pr):
     _lib.check(rc, "mgn_mp_project")
 
 
-def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, aggr, node_range=None):
+def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, aggr, node_range=None, edge_weight=None):
     """``node_range = (n0, n1, edge_count)`` restricts the launch to the receivers n0 .. n1-1 and
-    their ``edge_count`` in-edges (= rowptr[n1] - rowptr[n0], known to the caller on the host)."""
+    their ``edge_count`` in-edges (= rowptr[n1] - rowptr[n0], known to the caller on the host).
+    ``edge_weight`` [E] (CSR order): weights of the messages in the receivers' sums (attention)."""
     ne, n = e_in.shape[0], ps.shape[0]
     if mlp.in_dim != 3 * H or mlp.out_dim != H:
         raise RuntimeError("mp_edge: edge MLP must be 3H -> H -> H")
@@ -234,6 +235,16 @@ def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, 
         n_sub = n1 - n0
         if n_sub == 0 or e_sub == 0:
             return
+    if edge_weight is not None:
+        if node_range is not None:
+            raise RuntimeError("mp_edge: weighted messages are not combined with receiver sub-ranges")
+        rc = _lib.lib().mgn_mp_edge_weighted(
+            _dev(e_in, torch.float32, (ne, H), "e_in"), _dev(ps, torch.float32, (n, H), "ps"),
+            _dev(pr, torch.float32, (n, H), "pr"), rp, _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
+            _dev(csr_recv, torch.int32, (ne,), "csr_recv"), mlp.ref(), _dev(edge_weight, torch.float32, (ne,), "edge_weight"),
+            _opt(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (None, H), "aggr"), e_sub, n_sub, _stream())
+        _lib.check(rc, "mgn_mp_edge_weighted")
+        return
     rc = _lib.lib().mgn_mp_edge(_dev(e_in, torch.float32, (ne, H), "e_in"), _dev(ps, torch.float32, (n, H), "ps"),
                                 _dev(pr, torch.float32, (n, H), "pr"), rp,
                                 _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
@@ -241,6 +252,16 @@ def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, 
                                 _opt(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (None, H), "aggr"),
                                 e_sub, n_sub, _stream())
     _lib.check(rc, "mgn_mp_edge")
+
+
+def edge_attention(a_proj, rowptr, csr_sender, csr_recv, alpha, edge_weight):
+    """Message weights of the attention option from the projected node latents ``a_proj`` [N,H]."""
+    n, ne = a_proj.shape[0], csr_sender.shape[0]
+    rc = _lib.lib().mgn_edge_attention(_dev(a_proj, torch.float32, (n, H), "a_proj"), _dev(rowptr, torch.int32, (n + 1,), "rowptr"),
+                                       _dev(csr_sender, torch.int32, (ne,), "csr_sender"), _dev(csr_recv, torch.int32, (ne,), "csr_recv"),
+                                       _dev(alpha, torch.float32, (ne,), "alpha"), _dev(edge_weight, torch.float32, (ne,), "edge_weight"),
+                                       ne, n, _stream())
+    _lib.check(rc, "mgn_edge_attention")
 
 
 def mp_node(x, aggr, rowptr, mlp: MlpWeights, x_out):
@@ -370,6 +391,24 @@ def decode(x, mlp: MlpWeights, time_dim: int, out_dim: int, delta_norm=None, out
         _opt(phi, torch.float32, (n, 1), "phi"), _opt(node_type, torch.float32, (n, 5), "node_type"),
         _opt(pred, torch.float32, (time_dim, n, 3), "pred"), n, _stream())
     _lib.check(rc, "mgn_decode")
+
+
+def decode_cat(x, x2, w0, b0, w1, b1, time_dim: int, out_dim: int, hidden_ws, delta_norm=None, out_mean_std=None,
+               world_pos=None, phi=None, node_type=None, pred=None):
+    """:func:`decode` for a decoder whose first Linear reads cat[x, x2] (w0 is [H, 2H])."""
+    n = x.shape[0]
+    n_out = time_dim * out_dim
+    if n_out > MAX_DEC_OUT:
+        raise RuntimeError(f"decode_cat: {n_out} outputs exceed {MAX_DEC_OUT}")
+    c = MgnMlp(_dev(w0, torch.float32, (H, 2 * H), "w0"), _dev(b0, torch.float32, (H,), "b0"),
+               _dev(w1, torch.float32, (n_out, H), "w1"), _dev(b1, torch.float32, (n_out,), "b1"), 0, 0)
+    rc = _lib.lib().mgn_decode_cat(
+        _dev(x, torch.float32, (n, H), "x"), _dev(x2, torch.float32, (n, H), "x2"), C.byref(c), time_dim, out_dim,
+        _dev(hidden_ws, torch.float32, (n, H), "hidden_ws"), _opt(delta_norm, torch.float32, (time_dim, n, out_dim), "delta_norm"),
+        _opt(out_mean_std, torch.float32, (2 * n_out,), "out_mean_std"), _opt(world_pos, torch.float32, (n, 2), "world_pos"),
+        _opt(phi, torch.float32, (n, 1), "phi"), _opt(node_type, torch.float32, (n, 5), "node_type"),
+        _opt(pred, torch.float32, (time_dim, n, 3), "pred"), n, _stream())
+    _lib.check(rc, "mgn_decode_cat")
 
 
 def gather_rows(src, idx, dst):

@@ -128,6 +128,20 @@ int mgn_mp_edge(const float* e_in /*[E][H]*/, const float* ps, const float* pr,
                 const mgn_mlp* edge_mlp, float* e_out /*[E][H]*/, float* aggr /*[N][H]*/,
                 int64_t n_edges, int64_t n_nodes, void* stream);
 
+/* The same with weighted messages (attention, core/meshgraphnet.py:100-108): aggr[n] = sum of
+ * edge_weight[j] * (pre-residual output of edge j) over the in-edges j of n; e_out is not weighted (:120).
+ * edge_weight [E] in CSR order, from mgn_edge_attention. */
+int mgn_mp_edge_weighted(const float* e_in, const float* ps, const float* pr,
+                         const int32_t* rowptr, const int32_t* csr_sender, const int32_t* csr_recv,
+                         const mgn_mlp* edge_mlp, const float* edge_weight /*[E]*/, float* e_out, float* aggr,
+                         int64_t n_edges, int64_t n_nodes, void* stream);
+
+/* Attention weights (core/meshgraphnet.py:101-107): a_proj = attn_lin(x) [N][H] (any Linear kernel, e.g.
+ * mgn_train_linear_fwd); alpha[j] = leaky_relu(<a_proj[s_j], a_proj[r_j]>, 0.01) (scratch, [E]);
+ * edge_weight[j] = alpha[j] / max(sum of alpha over the in-edges of r_j, 1e-6), sums in CSR order. */
+int mgn_edge_attention(const float* a_proj, const int32_t* rowptr, const int32_t* csr_sender, const int32_t* csr_recv,
+                       float* alpha /*[E]*/, float* edge_weight /*[E]*/, int64_t n_edges, int64_t n_nodes, void* stream);
+
 /* Node update (:116-118): x_out = LN(ReLU(W1 ReLU(W0 cat[x, aggr] + b0) + b1)) + x.
  * aggr rows of nodes with rowptr[n] == rowptr[n+1] are read as zero.
  * x_out may alias x.                                                                  */
@@ -221,6 +235,14 @@ int mgn_decode(const float* x /*[N][H]*/, const mgn_mlp* dec, int32_t time_dim, 
                float* delta_norm /*[T][N][out_dim] or NULL*/,
                const float* out_mean_std, const float* world_pos, const float* phi, const float* node_type,
                float* pred /*[T][N][3] or NULL*/, int64_t n_nodes, void* stream);
+
+/* mgn_decode for the multiscale model, whose decoder reads cat[x, x2] (fine latents | coarse latents mapped back,
+ * core/meshgraphnet.py:192-194, :156): dec->w0 is [H][2H].  hidden_ws [N][H] is caller-provided scratch for the
+ * hidden activations. */
+int mgn_decode_cat(const float* x /*[N][H]*/, const float* x2 /*[N][H]*/, const mgn_mlp* dec, int32_t time_dim,
+                   int32_t out_dim, float* hidden_ws /*[N][H]*/, float* delta_norm, const float* out_mean_std,
+                   const float* world_pos, const float* phi, const float* node_type, float* pred, int64_t n_nodes,
+                   void* stream);
 
 /* Row gather / scatter used at the module boundary to move edge latents between the
  * caller's edge order and CSR order: dst[i] = src[idx[i]] (gather) or dst[idx[i]] = src[i]. */

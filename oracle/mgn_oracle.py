@@ -34,6 +34,7 @@ __all__ = [
     "init_state_dict", "mlp", "mp_layer", "mp_layer_csr_projected", "node_features",
     "edge_features", "forward", "predict", "loss", "rollout", "make_norms",
     "synthetic_graph", "bending_node_type", "state_dict_digest", "forced_relu_masks", "inject_noise",
+    "farthest_point_sampling", "knn_graph", "coarse_graph",
 ]
 
 
@@ -48,6 +49,9 @@ class OracleConfig:
     node_out_dim: int = 3
     with_mat_params: bool = False
     time_dim: int = 1
+    attention: bool = False            # core/meshgraphnet.py:60-61, :100-108
+    sample_ratio: float = 0.0          # > 0: coarse branch, core/meshgraphnet.py:148-156, :179-194, :237-283
+    coarse_process_steps: int = 0
 
 
 # --------------------------------------------------------------------------- edge build
@@ -134,12 +138,24 @@ def init_state_dict(cfg: OracleConfig, seed: int) -> "OrderedDict[str, torch.Ten
 
     for name, fin in (("node_encoder", cfg.node_in_dim), ("edge_encoder", cfg.edge_in_dim)):
         lin(f"{name}.0", fin, H); lin(f"{name}.2", H, H); ln(f"{name}.3")
+    def block(prefix):
+        if cfg.attention:                       # created before the two MLPs (core/meshgraphnet.py:60-61)
+            lin(f"{prefix}.attn_lin", H, H)
+        lin(f"{prefix}.edge_mlp.0", 3 * H, H); lin(f"{prefix}.edge_mlp.2", H, H)
+        ln(f"{prefix}.edge_mlp.4")
+        lin(f"{prefix}.node_mlp.0", 2 * H, H); lin(f"{prefix}.node_mlp.2", H, H)
+        ln(f"{prefix}.node_mlp.4")
+
     for i in range(cfg.process_steps):
-        lin(f"processors.{i}.edge_mlp.0", 3 * H, H); lin(f"processors.{i}.edge_mlp.2", H, H)
-        ln(f"processors.{i}.edge_mlp.4")
-        lin(f"processors.{i}.node_mlp.0", 2 * H, H); lin(f"processors.{i}.node_mlp.2", H, H)
-        ln(f"processors.{i}.node_mlp.4")
-    lin("node_decoder.0", H, H); lin("node_decoder.2", H, cfg.node_out_dim * cfg.time_dim)
+        block(f"processors.{i}")
+    if cfg.sample_ratio > 0:                    # core/meshgraphnet.py:148-156
+        lin("coarse_edge_encoder.0", cfg.edge_in_dim, H); lin("coarse_edge_encoder.2", H, H); ln("coarse_edge_encoder.3")
+        for i in range(cfg.coarse_process_steps):
+            block(f"coarse_processors.{i}")
+        lin("node_decoder.0", 2 * H, H)
+    else:
+        lin("node_decoder.0", H, H)
+    lin("node_decoder.2", H, cfg.node_out_dim * cfg.time_dim)
     return sd
 
 
@@ -192,9 +208,12 @@ class NormStats:
 
 def make_norms(cfg: OracleConfig) -> Dict[str, NormStats]:
     """Three fresh normalisers as the constructor makes them (core/meshgraphnet.py:165-167)."""
-    return {"node": NormStats.fresh(1, cfg.node_in_dim),
-            "edge": NormStats.fresh(1, cfg.edge_in_dim),
-            "output": NormStats.fresh(cfg.time_dim, cfg.node_out_dim)}
+    norms = {"node": NormStats.fresh(1, cfg.node_in_dim),
+             "edge": NormStats.fresh(1, cfg.edge_in_dim),
+             "output": NormStats.fresh(cfg.time_dim, cfg.node_out_dim)}
+    if cfg.sample_ratio > 0:                      # core/meshgraphnet.py:150
+        norms["coarse_edge"] = NormStats.fresh(1, cfg.edge_in_dim)
+    return norms
 
 
 # --------------------------------------------------------------------------- network
@@ -241,20 +260,76 @@ def mlp(sd, prefix: str, x: torch.Tensor, *, final_relu: bool, layer_norm: bool)
     return h
 
 
-def mp_layer(sd, i: int, x: torch.Tensor, edge_index: torch.Tensor, e: torch.Tensor):
-    """One processor block, attention off (core/meshgraphnet.py:92-120).
+def mp_layer(sd, i, x: torch.Tensor, edge_index: torch.Tensor, e: torch.Tensor):
+    """One processor block (core/meshgraphnet.py:92-120).  ``i`` is the index into ``processors`` or a full key
+    prefix such as ``"coarse_processors.1"``.
 
     The aggregated message is the pre-residual edge output (:110-113); the node MLP
-    sees the old node latents (:116); residuals are added last (:118, :120).
+    sees the old node latents (:116); residuals are added last (:118, :120).  With an
+    ``attn_lin`` in the block (:60-61) the messages are weighted as :100-108 does: the leaky-ReLU of the dot
+    product of the two projected end points, divided by its sum over the receiver's in-edges (clamped at 1e-6).
     """
+    p = i if isinstance(i, str) else f"processors.{i}"
     snd, rcv = edge_index[0], edge_index[1]
-    e_new = mlp(sd, f"processors.{i}.edge_mlp", torch.cat([x[snd], x[rcv], e], dim=-1),
+    e_new = mlp(sd, f"{p}.edge_mlp", torch.cat([x[snd], x[rcv], e], dim=-1),
                 final_relu=True, layer_norm=True)
+    msg = e_new
+    if f"{p}.attn_lin.weight" in sd:
+        a = F.linear(x, sd[f"{p}.attn_lin.weight"], sd[f"{p}.attn_lin.bias"])
+        alpha = F.leaky_relu((a[snd] * a[rcv]).sum(dim=-1))
+        denom = alpha.new_zeros(x.shape[0]).scatter_add_(0, rcv, alpha)
+        denom[rcv] = denom[rcv].clamp(min=1e-6)
+        msg = e_new * (alpha / denom[rcv]).unsqueeze(-1)
     aggr = e_new.new_zeros(x.shape[0], e_new.shape[1])
-    aggr.scatter_add_(0, rcv.view(-1, 1).expand_as(e_new), e_new)
-    x_new = mlp(sd, f"processors.{i}.node_mlp", torch.cat([x, aggr], dim=-1),
+    aggr.scatter_add_(0, rcv.view(-1, 1).expand_as(msg), msg)
+    x_new = mlp(sd, f"{p}.node_mlp", torch.cat([x, aggr], dim=-1),
                 final_relu=True, layer_norm=True)
     return x_new + x, e_new + e
+
+
+def farthest_point_sampling(points: torch.Tensor, num_samples: int, start: int) -> torch.Tensor:
+    """core/meshgraphnet.py:243-254 with the random first index (:248) passed in."""
+    n = points.shape[0]
+    idx = torch.zeros(num_samples, dtype=torch.long)
+    idx[0] = start
+    dist = torch.full((n,), float("inf"))
+    for k in range(1, num_samples):
+        last = points[idx[k - 1]].unsqueeze(0)
+        dist = torch.minimum(dist, torch.norm(points - last, dim=-1))
+        idx[k] = torch.argmax(dist)
+    return idx
+
+
+def knn_graph(points: torch.Tensor, k: int) -> torch.Tensor:
+    """Restatement of ``torch_geometric.nn.knn_graph(x, k, loop=False)`` (torch-cluster 1.6.3, absent here; no
+    vector of the reference pins it): for every point its k nearest other points by Euclidean distance, nearest
+    first, ties by lower index; edge = (neighbour -> point), edges grouped by point in ascending point order.
+    Squared distances are formed coordinate by coordinate in float64, so equal distances compare equal."""
+    n = points.shape[0]
+    p = points.double()
+    diff = p.unsqueeze(1) - p.unsqueeze(0)
+    d2 = (diff * diff).sum(dim=-1) if p.shape[1] != 2 else diff[..., 0] * diff[..., 0] + diff[..., 1] * diff[..., 1]
+    d2.fill_diagonal_(float("inf"))
+    kk = min(k, n - 1)
+    order = torch.argsort(d2, dim=1, stable=True)[:, :kk]
+    centre = torch.arange(n).unsqueeze(1).expand(n, kk)
+    return torch.stack([order.reshape(-1), centre.reshape(-1)])
+
+
+def coarse_graph(cfg: OracleConfig, g, start: int):
+    """(coarse edge features [Ec,7], coarse edge_index [2,Ec] in coarse numbering, first_indices [Nc]):
+    core/meshgraphnet.py:237-283."""
+    mesh_pos, world_pos, phi = g["mesh_pos"], g["world_pos"], g["phi"]
+    k = 4 if mesh_pos.shape[-1] == 3 else 3
+    n_coarse = max(1, int(mesh_pos.shape[0] * cfg.sample_ratio))
+    first = farthest_point_sampling(mesh_pos, n_coarse, start)
+    cei = knn_graph(mesh_pos[first], k)
+    s, r = first[cei[0]], first[cei[1]]
+    rel = mesh_pos[s] - mesh_pos[r]
+    relw = world_pos[s] - world_pos[r]
+    feats = torch.cat([rel, torch.norm(rel, dim=-1, keepdim=True), relw, torch.norm(relw, dim=-1, keepdim=True),
+                       phi[s] - phi[r]], dim=-1)
+    return feats, cei, first
 
 
 def mp_layer_csr_projected(sd, i: int, x: torch.Tensor, rowptr, sender, recv, e_csr: torch.Tensor):
@@ -302,7 +377,7 @@ def edge_features(g) -> torch.Tensor:
                       g["phi"][s] - g["phi"][r]], dim=-1)
 
 
-def forward(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g, *, return_latents: bool = False):
+def forward(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g, *, return_latents: bool = False, coarse_start: int = 0):
     """Normalised delta prediction [T, N, out] (core/meshgraphnet.py:168-211, fine path
     only: sample_ratio == 0).  Both feature normalisers accumulate on every call."""
     x = node_features(cfg, g).unsqueeze(0)
@@ -310,8 +385,19 @@ def forward(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g, *, return_lat
     x_h = mlp(sd, "node_encoder", norms["node"].normalize(x), final_relu=False, layer_norm=True).squeeze(0)
     e_h = mlp(sd, "edge_encoder", norms["edge"].normalize(e), final_relu=False, layer_norm=True).squeeze(0)
     x0, e0 = x_h, e_h
+    if cfg.sample_ratio > 0:                                    # core/meshgraphnet.py:179-182
+        ce, cei, first = coarse_graph(cfg, g, coarse_start)
+        ce_h = mlp(sd, "coarse_edge_encoder", norms["coarse_edge"].normalize(ce.unsqueeze(0)), final_relu=False,
+                   layer_norm=True).squeeze(0)
+        cx_h = x_h[first]
     for i in range(cfg.process_steps):
         x_h, e_h = mp_layer(sd, i, x_h, g["edge_index"], e_h)
+    if cfg.sample_ratio > 0:                                    # :187-194
+        for i in range(cfg.coarse_process_steps):
+            cx_h, ce_h = mp_layer(sd, f"coarse_processors.{i}", cx_h, cei, ce_h)
+        map_back = torch.zeros_like(x_h)
+        map_back[first] = cx_h
+        x_h = torch.cat([x_h, map_back], dim=-1)
     dec = mlp(sd, "node_decoder", x_h, final_relu=False, layer_norm=False)
     delta = dec.view(-1, cfg.time_dim, cfg.node_out_dim).permute(1, 0, 2)
     dt = torch.arange(1, cfg.time_dim + 1).view(cfg.time_dim, 1, 1)
@@ -321,10 +407,10 @@ def forward(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g, *, return_lat
     return out
 
 
-def predict(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g) -> torch.Tensor:
+def predict(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g, coarse_start: int = 0) -> torch.Tensor:
     """Next state(s) [T, N, 3] (core/meshgraphnet.py:305-317)."""
     with torch.no_grad():
-        delta = norms["output"].inverse(forward(sd, cfg, norms, g))
+        delta = norms["output"].inverse(forward(sd, cfg, norms, g, coarse_start=coarse_start))
         cur = torch.cat([g["world_pos"], g["phi"]], dim=-1)
         for k in range(3):
             delta[:, g["node_type"][:, k + 1] == 1, k] = 0.0
@@ -345,7 +431,7 @@ def loss(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g):
     return parts[0] + parts[1] + parts[2], parts[0], parts[1], parts[2]
 
 
-def rollout(sd, cfg: OracleConfig, norms: Dict[str, NormStats], static, world_pos, phi, swelling):
+def rollout(sd, cfg: OracleConfig, norms: Dict[str, NormStats], static, world_pos, phi, swelling, coarse_start: int = 0):
     """Autoregressive rollout (core/rollout.py:5-45).
 
     ``static`` holds mesh_pos / node_type / mat_param / edge_index; ``world_pos`` [T,N,2],
@@ -361,7 +447,7 @@ def rollout(sd, cfg: OracleConfig, norms: Dict[str, NormStats], static, world_po
     for t in range(0, T, Td):
         cols = [swelling[t + w] if t + w < T else torch.zeros_like(swelling[0]) for w in range(Td + 1)]
         g["swelling_phi"] = torch.stack(cols).T
-        p = predict(sd, cfg, norms, g)
+        p = predict(sd, cfg, norms, g, coarse_start=coarse_start)
         last = p[-1].clone()
         g["world_pos"], g["phi"] = last[:, :2], last[:, 2:]
         out.append(p)

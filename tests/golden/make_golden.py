@@ -61,7 +61,8 @@ def _install_shims():
         key = torch.unique(row * n + col)
         return torch.stack([torch.div(key, n, rounding_mode="floor"), key % n])
 
-    tgn.MessagePassing, tgn.knn_graph = object, None
+    # torch_cluster's knn_graph is absent: the oracle's restatement stands in (only the multiscale fixture calls it)
+    tgn.MessagePassing, tgn.knn_graph = object, (lambda x, k, loop=False: O.knn_graph(x, k))
     tgu.softmax, tgu.to_undirected = None, to_undirected
     tgd.Data = Frame               # core/datasetclass.py builds its frames with Data(**fields)
     tg.nn, tg.utils, tg.data = tgn, tgu, tgd
@@ -344,6 +345,51 @@ def g6_dataset():
     print("g6 dataset frames ok:", sorted(k for k in out if k.endswith("_n_frames")))
 
 
+def g7_attention_multiscale():
+    """The two options no shipped config enables, through the reference's own forward / predict
+    (core/meshgraphnet.py:100-108, :179-194, :237-283): attention alone, the coarse branch alone, and both.
+    The random first index of the farthest-point sampling (:248) is fixed by torch.manual_seed right before each
+    call and recorded; knn_graph is the oracle's restatement on both sides (see _install_shims)."""
+    g = O.synthetic_graph(12, 8, seed=4)
+    n = g["mesh_pos"].shape[0]
+    out = {"nx": 12, "ny": 8, "graph_seed": 4}
+    for tag, att, ratio, csteps in (("att", True, 0.0, 0), ("ms", False, 0.5, 2), ("both", True, 0.4, 2)):
+        cfg = O.OracleConfig(process_steps=3, attention=att, sample_ratio=ratio, coarse_process_steps=csteps)
+        torch.manual_seed(21)
+        m = EncodeProcessDecodeMultiScale(cfg.node_in_dim, cfg.edge_in_dim, hidden_size=128, process_steps=3,
+                                          coarse_process_steps=csteps, node_out_dim=3, attention=att,
+                                          with_mat_params=False, sample_ratio=ratio, time_dim=1, device="cpu")
+        sd = O.init_state_dict(cfg, 21)
+        rsd = m.state_dict()
+        assert list(rsd.keys()) == list(sd.keys()), (tag, "state_dict key order differs")
+        for k in sd:
+            assert bit_equal(rsd[k], sd[k]), (tag, k)
+        norms = O.make_norms(cfg)
+        with torch.no_grad():
+            torch.manual_seed(5)
+            start1 = int(torch.randint(0, n, (1,)))
+            torch.manual_seed(5)
+            rf = m.forward(g)
+            of = O.forward(sd, cfg, norms, g, coarse_start=start1)
+            assert bit_equal(rf, of), tag
+            torch.manual_seed(6)
+            start2 = int(torch.randint(0, n, (1,)))
+            torch.manual_seed(6)
+            rp = m.predict(g)
+            op = O.predict(sd, cfg, norms, g, coarse_start=start2)
+            assert bit_equal(rp, op), tag
+        out.update({f"{tag}_forward": rf.numpy(), f"{tag}_predict2": rp.numpy(), f"{tag}_start1": start1, f"{tag}_start2": start2,
+                    f"{tag}_sd_digest": O.state_dict_digest(sd), f"{tag}_n_keys": len(sd)})
+        if ratio > 0:
+            ce, cei, first = O.coarse_graph(cfg, g, start1)
+            out.update({f"{tag}_first1": first.numpy(), f"{tag}_coarse_edge_index1": cei.numpy()})
+            rn = m.coarse_edge_features_normalizer
+            assert bit_equal(rn._acc_sum, norms["coarse_edge"].acc_sum) and rn._acc_count == norms["coarse_edge"].acc_count
+            out.update(norm_stats_arrays(f"{tag}_out_coarse_edge", rn))
+    np.savez_compressed(os.path.join(HERE, "g7_attention_multiscale.npz"), **out)
+    print("g7_attention_multiscale: ok")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                       # regenerate only the named fixtures, e.g. `make_golden.py g6_dataset`
@@ -357,4 +403,5 @@ if __name__ == "__main__":
     g4_loss_grads()
     g5_rollout()
     g6_dataset()
+    g7_attention_multiscale()
     print("all fixtures written to", HERE)

@@ -239,9 +239,12 @@ def test_checkpoint_roundtrip(tmp_path):
 def test_unsupported_options_raise():
     from gnn_amd.meshgraphnet import EncodeProcessDecodeMultiScale
     with pytest.raises(NotImplementedError):
-        EncodeProcessDecodeMultiScale(10, 7, sample_ratio=0.5, node_out_dim=3)
-    with pytest.raises(NotImplementedError):
-        EncodeProcessDecodeMultiScale(10, 7, sample_ratio=0.0, attention=True, node_out_dim=3)
+        EncodeProcessDecodeMultiScale(10, 7, hidden_size=64, sample_ratio=0.0, node_out_dim=3)
+    g = O.synthetic_graph(4, 3, with_target=True)
+    for kw in (dict(sample_ratio=0.5, coarse_process_steps=1), dict(sample_ratio=0.0, attention=True)):
+        mm = EncodeProcessDecodeMultiScale(10, 7, node_out_dim=3, with_mat_params=False, process_steps=1, device=DEV, **kw).to(DEV)
+        with pytest.raises(NotImplementedError):        # the two options run in forward / predict only
+            mm.loss(graph_to(g, DEV))
     m = EncodeProcessDecodeMultiScale(10, 7, sample_ratio=0.0, node_out_dim=3, with_mat_params=False, process_steps=1)
     with pytest.raises(RuntimeError):       # CPU tensors: no fallback
         m.predict(O.synthetic_graph(2, 2))

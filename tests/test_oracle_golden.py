@@ -2,6 +2,7 @@
 Integer results must be identical; float results are compared at 2e-6 (the fixtures were
 bit-identical in the process that wrote them, but another host may pick another CPU
 kernel / thread split inside torch)."""
+import pytest
 import numpy as np
 import torch
 
@@ -134,3 +135,24 @@ def test_rollout_golden():
     ref = torch.from_numpy(d5["pred"][:T])
     assert pred.shape == ref.shape and rel_l2(pred, ref) < 1e-5
     assert torch.equal(pred[0], torch.cat([torch.from_numpy(d5["world_pos"][0]), torch.from_numpy(d5["phi"][0])], -1))
+
+
+@pytest.mark.parametrize("tag,att,ratio,csteps", [("att", True, 0.0, 0), ("ms", False, 0.5, 2), ("both", True, 0.4, 2)])
+def test_oracle_attention_and_multiscale_golden(tag, att, ratio, csteps):
+    """Fixture G7: forward / predict of the reference model with the attention option, the coarse multiscale branch,
+    and both (core/meshgraphnet.py:100-108, :179-194, :237-283), bit for bit."""
+    d = np.load(f"{GOLDEN}/g7_attention_multiscale.npz")
+    cfg = O.OracleConfig(process_steps=3, attention=att, sample_ratio=ratio, coarse_process_steps=csteps)
+    sd = O.init_state_dict(cfg, 21)
+    assert len(sd) == int(d[f"{tag}_n_keys"])
+    assert abs(O.state_dict_digest(sd) - float(d[f"{tag}_sd_digest"])) < 1e-9 * abs(float(d[f"{tag}_sd_digest"]))
+    g = O.synthetic_graph(int(d["nx"]), int(d["ny"]), seed=int(d["graph_seed"]))
+    norms = O.make_norms(cfg)
+    with torch.no_grad():
+        f = O.forward(sd, cfg, norms, g, coarse_start=int(d[f"{tag}_start1"]))
+        p = O.predict(sd, cfg, norms, g, coarse_start=int(d[f"{tag}_start2"]))
+    assert torch.equal(f, torch.from_numpy(d[f"{tag}_forward"])) and torch.equal(p, torch.from_numpy(d[f"{tag}_predict2"]))
+    if ratio > 0:
+        ce, cei, first = O.coarse_graph(cfg, g, int(d[f"{tag}_start1"]))
+        assert np.array_equal(first.numpy(), d[f"{tag}_first1"]) and np.array_equal(cei.numpy(), d[f"{tag}_coarse_edge_index1"])
+        assert norms["coarse_edge"].acc_count == int(d[f"{tag}_out_coarse_edge_count"])
