@@ -245,13 +245,24 @@ __device__ __forceinline__ void hplanes_store4(unsigned short* tile, int plane, 
 template <int KS>
 struct WPlanesH { u32x4 p[2][KS]; };
 
+// Two phases, so that a kernel with several weight sets can have all their loads in flight before the first
+// conversion (the raw fp32 values wait in the registers the planes will occupy: 8 values = 8 registers either way):
+// load_wraw_h issues the loads, split_wraw_h converts in place.
 template <int KS>
-__device__ __forceinline__ void load_wplanes_h(WPlanesH<KS>& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
+__device__ __forceinline__ void load_wraw_h(WPlanesH<KS>& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
     const float* row = W + (size_t)feat * ldw + koff + 8 * h;
-    float m = 0.f;
 #pragma unroll
     for (int c = 0; c < KS; ++c) {
-        const f32x4 lo4 = *(const f32x4*)(row + 16 * c) * W_SCALE, hi4 = *(const f32x4*)(row + 16 * c + 4) * W_SCALE;
+        w.p[0][c] = __builtin_bit_cast(u32x4, *(const f32x4*)(row + 16 * c));
+        w.p[1][c] = __builtin_bit_cast(u32x4, *(const f32x4*)(row + 16 * c + 4));
+    }
+}
+
+template <int KS>
+__device__ __forceinline__ void split_wraw_h(WPlanesH<KS>& w, float& m) {
+#pragma unroll
+    for (int c = 0; c < KS; ++c) {
+        const f32x4 lo4 = __builtin_bit_cast(f32x4, w.p[0][c]) * W_SCALE, hi4 = __builtin_bit_cast(f32x4, w.p[1][c]) * W_SCALE;
         track4(m, lo4); track4(m, hi4);
         u32x2 a1, a2, b1, b2;
         split2_pack4(lo4, a1, a2);
@@ -259,6 +270,13 @@ __device__ __forceinline__ void load_wplanes_h(WPlanesH<KS>& w, const float* __r
         w.p[0][c] = u32x4{a1[0], a1[1], b1[0], b1[1]};
         w.p[1][c] = u32x4{a2[0], a2[1], b2[0], b2[1]};
     }
+}
+
+template <int KS>
+__device__ __forceinline__ void load_wplanes_h(WPlanesH<KS>& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
+    float m = 0.f;
+    load_wraw_h<KS>(w, W, ldw, koff, feat, h);
+    split_wraw_h<KS>(w, m);
     range_report(m);                                // a weight of 512 or more (after the pre-scale) is out of range too
 }
 
@@ -434,13 +452,25 @@ __device__ __forceinline__ int range_of_block(int b, int nb) {
     return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3);
 }
 
-__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int n, long long target) {
-    int lo = 0, hi = n;                       // first index with a[i] >= target, in [0, n]
+// Edge range of this workgroup, cut at receiver boundaries: [rowptr[i0], rowptr[i1]) with i = first index whose
+// rowptr reaches the block's share of the edges.  Called by all 64 lanes of ONE wave: lanes 0..31 look for the
+// lower end, lanes 32..63 for the upper end, each half with a 33-way search (32 probes per round trip to memory:
+// five rounds at a million receivers, where a binary search by one thread makes forty dependent loads -- tens of
+// microseconds during which the workgroup only waits).
+__device__ __forceinline__ void block_edge_range(const int* __restrict__ rowptr, int n_nodes, long long n_edges, int* srange) {
+    const int lane = threadIdx.x & 63, half = lane >> 5, sub = lane & 31;
+    const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
+    const long long key = (long long)rowptr[0] + (long long)(rho + half) * n_edges / nb;   // rowptr may start inside a larger CSR
+    int lo = 0, hi = n_nodes;                 // answer in [lo, hi]; rowptr[hi] >= key holds (rowptr[n_nodes] = first + n_edges)
     while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if ((long long)a[mid] < target) lo = mid + 1; else hi = mid;
+        const int step = (hi - lo + 32) / 33;                     // ceil(span / 33) >= 1
+        const int p = lo + (sub + 1) * step - 1;                  // probes lo+step-1, lo+2*step-1, ...
+        const bool less = p < hi && (long long)rowptr[p] < key;   // monotone: the true flags form a prefix
+        const int cnt = __popc((unsigned)(__ballot(less) >> (32 * half)));
+        hi = cnt < 32 ? min(hi, lo + (cnt + 1) * step - 1) : hi;  // the first probe that is not less bounds the answer
+        lo += cnt * step;                                         // everything up to the last "less" probe is below it
     }
-    return lo;
+    if (sub == 0) srange[half] = rowptr[lo];
 }
 
 // ------------------------------------------------------------------------ host helpers

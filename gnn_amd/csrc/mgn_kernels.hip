@@ -64,13 +64,7 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_kernel(EdgeArgs a) {
     load_wfrag<16>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
     load_wfrag<16>(wb, a.w1, H, 0, 32 * w + j, h);
     if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; }
-    if (t == 0) {
-        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
-        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
-        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
-        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
-    }
+    if (t < 64) block_edge_range(a.rowptr, a.n_nodes, a.n_edges, srange);   // wave 0, all of its lanes
     __syncthreads();
     const int e0 = srange[0], e1 = srange[1];
     if (e0 >= e1) return;
@@ -206,13 +200,7 @@ __global__ __launch_bounds__(NT3, 2) void mp_edge3_kernel(EdgeArgs a) {
     const int j = lane & 31, h = lane >> 5;
 
     if (t < H) { vec[0][t] = a.b1[t]; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
-    if (t == 0) {
-        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
-        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
-        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
-        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
-    }
+    if (t < 64) block_edge_range(a.rowptr, a.n_nodes, a.n_edges, srange);   // wave 0, all of its lanes
     __syncthreads();
     const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
     if (e0 >= e1) return;
@@ -413,20 +401,19 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
     static_assert(sizeof(Hp) >= sizeof(float) * tile_floats(H / 4), "Os must fit into Hp");
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    // wave 0 looks up the edge range first: its round trips to memory overlap the other waves' weight loads
+    if (t < 64) block_edge_range(a.rowptr, a.n_nodes, a.n_edges, srange);
     WPlanesH<8> wa, wb;
-    load_wplanes_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
-    load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
+    load_wraw_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
+    load_wraw_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
     if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
-    if (t == 0) {
-        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long first = a.rowptr[0];         // rowptr may start inside a larger CSR (receiver sub-range)
-        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
-        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
-        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
-    }
+    __builtin_amdgcn_sched_barrier(0);               // all loads in flight before the first conversion
+    split_wraw_h<8>(wa, rmax);
+    split_wraw_h<8>(wb, rmax);
     __syncthreads();
     const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
-    if (e0 >= e1) return;
+    if (e0 >= e1) { range_report(rmax); return; }
     const int last = e1 - e0 - 1;                    // row offsets are relative to e0 and clamped to [0, last]
     const float* ein_g = a.e_in + (size_t)e0 * H;
     float* eout_g = a.e_out ? a.e_out + (size_t)e0 * H : nullptr;      // no edge output: never dereferenced
@@ -440,7 +427,6 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) cur[it] = *(const f32x4*)(ein_g + (unsigned)(min(srow + 8 * it, last) * H + 4 * sq));
     int s_cur = snd_g[min(j, last)], r_cur = rcv_g[min(j, last)];
-    float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
 #pragma unroll
     for (int it = 0; it < 4; ++it) hplanes_store4(Xp[0], PLH, PKH, srow + 8 * it, 4 * sq, cur[it], rmax);
     __syncthreads();
@@ -613,15 +599,17 @@ __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
 
     f32x4 px[4], pa[4];
     auto prefetch = [&](int tile) {
+        int deg[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int n = min(tile * TM + srow + 8 * it, nlast);
             px[it] = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
-            // aggr rows of nodes without in-edges were never written: read them as zero
-            const bool has = a.rowptr[n + 1] > a.rowptr[n];
-            const f32x4 av = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
-            pa[it] = has ? av : f32x4{0.f, 0.f, 0.f, 0.f};
+            deg[it] = a.rowptr[n + 1] - a.rowptr[n];
+            pa[it] = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
         }
+        // aggr rows of nodes without in-edges were never written: read them as zero (all loads first, then the selects)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) pa[it] = deg[it] > 0 ? pa[it] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
     prefetch(t0);
     __syncthreads();
@@ -699,18 +687,6 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
     __shared__ float red[16 * TM];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
-    WPlanesH<16> wa;
-    WPlanesH<8> wb, ws, wr;
-    load_wplanes_h<16>(wa, a.w0, 2 * H, 0, 32 * w + j, h);
-    load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
-    if constexpr (PROJ) {
-        load_wplanes_h<8>(ws, a.nw0, 3 * H, 0, 32 * w + j, h);
-        load_wplanes_h<8>(wr, a.nw0, 3 * H, H, 32 * w + j, h);
-    }
-    if (t < H) {
-        vec[0][t] = a.b0[t]; vec[1][t] = a.b1[t]; vec[2][t] = a.ln_w[t]; vec[3][t] = a.ln_b[t];
-        vec[4][t] = PROJ ? a.nb0[t] : 0.f;
-    }
     const int ntiles = (a.n_nodes + TM - 1) / TM;
     const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
     const int t0 = (int)((long long)rho * ntiles / nb), t1 = (int)((long long)(rho + 1) * ntiles / nb);
@@ -721,16 +697,43 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
 
     f32x4 px[4], pa[4];
     auto prefetch = [&](int tile) {
+        int deg[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int n = min(tile * TM + srow + 8 * it, nlast);
             px[it] = *(const f32x4*)(a.x + (size_t)n * H + 4 * sq);
-            // aggr rows of nodes without in-edges were never written: read them as zero
-            const bool has = a.rowptr[n + 1] > a.rowptr[n];
-            const f32x4 av = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
-            pa[it] = has ? av : f32x4{0.f, 0.f, 0.f, 0.f};
+            deg[it] = a.rowptr[n + 1] - a.rowptr[n];
+            pa[it] = *(const f32x4*)(a.aggr + (size_t)n * H + 4 * sq);
         }
+        // aggr rows of nodes without in-edges were never written: read them as zero (all loads first, then the selects)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) pa[it] = deg[it] > 0 ? pa[it] : f32x4{0.f, 0.f, 0.f, 0.f};
     };
+    WPlanesH<16> wa;
+    WPlanesH<8> wb, ws, wr;
+    // all weight loads in flight before the first conversion (converted one set at a time, with this kernel's
+    // register file full, the later sets load two values per round trip to memory)
+    load_wraw_h<16>(wa, a.w0, 2 * H, 0, 32 * w + j, h);
+    load_wraw_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    if constexpr (PROJ) {
+        load_wraw_h<8>(ws, a.nw0, 3 * H, 0, 32 * w + j, h);
+        load_wraw_h<8>(wr, a.nw0, 3 * H, H, 32 * w + j, h);
+    }
+    float v5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (t < H) { v5[0] = a.b0[t]; v5[1] = a.b1[t]; v5[2] = a.ln_w[t]; v5[3] = a.ln_b[t]; v5[4] = PROJ ? a.nb0[t] : 0.f; }
+    prefetch(t0);                                    // first tile's rows: in flight with the weights
+    __builtin_amdgcn_sched_barrier(0);
+    if (t < H) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) vec[k][t] = v5[k];
+    }
+    {
+        float m = 0.f;
+        split_wraw_h<16>(wa, m);
+        split_wraw_h<8>(wb, m);
+        if constexpr (PROJ) { split_wraw_h<8>(ws, m); split_wraw_h<8>(wr, m); }
+        range_report(m);
+    }
     // accumulator (W_SCALE * product) -> value: acc * W_UNSCALE + bias, optional ReLU
     auto finish = [&](f32x16 acc, const float* bias, bool relu) {
 #pragma unroll
@@ -753,7 +756,6 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
             hplanes_store4(tile, PL, PKH, j, 32 * w + 8 * g + 4 * h, f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, m);
         range_report(m);
     };
-    prefetch(t0);
     __syncthreads();
     STAMP_DECL
     for (int tile = t0; tile < t1; ++tile) {
@@ -1179,7 +1181,7 @@ constexpr int SUM_BLOCKS_MAX = 1024;
 
 __global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* __restrict__ feat, long long rows,
                                                                   int F, double* __restrict__ partial) {
-    __shared__ double sh[NT];
+    __shared__ double sh[NT / 64][2 * MGN_MAX_FEAT];
     const long long per = (rows + gridDim.x - 1) / gridDim.x;
     const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
     double s[MGN_MAX_FEAT], q[MGN_MAX_FEAT];
@@ -1190,18 +1192,23 @@ __global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* _
         for (int k = 0; k < MGN_MAX_FEAT; ++k)
             if (k < F) { const double v = feat[r * F + k]; s[k] += v; q[k] += v * v; }
     }
+    // fixed order: butterfly within each wave, then the four wave sums in wave order (one barrier in all)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 2 * MGN_MAX_FEAT; ++k) {
-        const int kk = k % MGN_MAX_FEAT;
-        if (kk >= F) continue;
-        sh[threadIdx.x] = (k < MGN_MAX_FEAT) ? s[kk] : q[kk];
-        __syncthreads();
-        for (int off = NT / 2; off > 0; off >>= 1) {
-            if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 2 * MGN_MAX_FEAT + k] = sh[0];
-        __syncthreads();
+    for (int k = 0; k < MGN_MAX_FEAT; ++k) {
+        if (k >= F) continue;
+        double a = s[k], b = q[k];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) { a += __shfl_xor(a, m, 64); b += __shfl_xor(b, m, 64); }
+        if (lane == 0) { sh[wv][k] = a; sh[wv][MGN_MAX_FEAT + k] = b; }
+    }
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < 2 * MGN_MAX_FEAT && (k % MGN_MAX_FEAT) < F) {
+        double tot = sh[0][k];
+#pragma unroll
+        for (int v = 1; v < NT / 64; ++v) tot += sh[v][k];
+        partial[(size_t)blockIdx.x * 2 * MGN_MAX_FEAT + k] = tot;
     }
 }
 

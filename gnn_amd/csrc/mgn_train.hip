@@ -541,13 +541,7 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
     load_wplanes_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
     load_wplanes32_t(w2t, a.w1, H, 32 * w + j, h);
     if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; tcarry[t] = 0.f; }
-    if (t == 0) {
-        const int nb = gridDim.x, rho = range_of_block(blockIdx.x, nb);
-        const long long first = a.rowptr[0];
-        const long long lo = first + (long long)rho * a.n_edges / nb, hi = first + (long long)(rho + 1) * a.n_edges / nb;
-        srange[0] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, lo)];
-        srange[1] = a.rowptr[lower_bound_i32(a.rowptr, a.n_nodes + 1, hi)];
-    }
+    if (t < 64) block_edge_range(a.rowptr, a.n_nodes, a.n_edges, srange);   // wave 0, all of its lanes
     f32x16 dw2[4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) dw2[kb] = zero16();
