@@ -19,6 +19,11 @@ class MgnMlp(C.Structure):
                 ("ln_w", C.c_void_p), ("ln_b", C.c_void_p)]
 
 
+class MgnWeightSlice(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("ld", C.c_int32), ("col0", C.c_int32), ("k", C.c_int32), ("reserved", C.c_int32)]
+
+
+MAX_PACK_SLICES = 112                   # MGN_MAX_PACK_SLICES
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _MLP = C.POINTER(MgnMlp)
 
@@ -40,6 +45,10 @@ SIGNATURES = {
     "mgn_mp_edge_weighted": (C.c_int, [_P, _P, _P, _P, _P, _P, _MLP, _P, _P, _P, _I64, _I64, _P]),
     "mgn_edge_attention": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "mgn_decode_cat": (C.c_int, [_P, _P, _MLP, _I32, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgn_packed_weight_bytes": (_I64, [_I32]),
+    "mgn_pack_weights": (C.c_int, [C.POINTER(MgnWeightSlice), _I32, _P, _P]),
+    "mgn_mp_edge_packed": (C.c_int, [_P, _P, _P, _P, _P, _P, _MLP, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mgn_mp_node_packed": (C.c_int, [_P, _P, _P, _MLP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_mp_node": (C.c_int, [_P, _P, _P, _MLP, _P, _I64, _P]),
     "mgn_mp_node_project": (C.c_int, [_P, _P, _P, _MLP, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_node_features": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),

@@ -272,6 +272,18 @@ __device__ __forceinline__ void split_wraw_h(WPlanesH<KS>& w, float& m) {
     }
 }
 
+// The same planes prepared once per weight set (pack_weights_kernel): u32x4 [4 waves][KS][2 planes][64 lanes], i.e.
+// every register quad of every lane stored where a fully coalesced 1-KiB load finds it.  Loading a set from the
+// row-major fp32 matrix takes 32 bytes out of each 128-byte line per instruction (every lane is its own row) and
+// costs a workgroup 1.5 us per 128 x 128 set before its first tile; from the packed block it costs a third of that
+// and no conversion (scripts/micro/prologue.hip) -- what matters when a launch has one tile per workgroup.
+template <int KS>
+__device__ __forceinline__ void load_wpacked_h(WPlanesH<KS>& w, const void* __restrict__ packed, int wave, int lane) {
+    const u32x4* p = (const u32x4*)packed + (size_t)wave * KS * 2 * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < KS; ++c) { w.p[0][c] = p[(2 * c) * 64]; w.p[1][c] = p[(2 * c + 1) * 64]; }
+}
+
 template <int KS>
 __device__ __forceinline__ void load_wplanes_h(WPlanesH<KS>& w, const float* __restrict__ W, int ldw, int koff, int feat, int h) {
     float m = 0.f;

@@ -47,6 +47,7 @@ struct EdgeArgs {
     float* e_out; float* aggr;
     int n_edges; int n_nodes;
     const float* ew;                 // ATT kernels: per-edge weight of the message in the receiver's sum (attention)
+    const void* pk0; const void* pk1;    // fp16-split path: w0[:, 2H:] and w1 as packed planes (pack_weights_kernel), or null
 };
 
 template <bool ATT>
@@ -405,12 +406,12 @@ __global__ __launch_bounds__(NT, 2) void mp_edge_h4_kernel(EdgeArgs a) {
     if (t < 64) block_edge_range(a.rowptr, a.n_nodes, a.n_edges, srange);
     WPlanesH<8> wa, wb;
     float rmax = 0.f;                                // largest magnitude this thread has split (range guard)
-    load_wraw_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h);
-    load_wraw_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+    const bool packed = a.pk0 != nullptr;            // weight planes prepared by pack_weights_kernel (range checked there)
+    if (packed) { load_wpacked_h<8>(wa, a.pk0, w, lane); load_wpacked_h<8>(wb, a.pk1, w, lane); }
+    else { load_wraw_h<8>(wa, a.w0, 3 * H, 2 * H, 32 * w + j, h); load_wraw_h<8>(wb, a.w1, H, 0, 32 * w + j, h); }
     if (t < H) { vec[0][t] = a.b1[t] * W_SCALE; vec[1][t] = a.ln_w[t]; vec[2][t] = a.ln_b[t]; tcarry[t] = 0.f; }
     __builtin_amdgcn_sched_barrier(0);               // all loads in flight before the first conversion
-    split_wraw_h<8>(wa, rmax);
-    split_wraw_h<8>(wb, rmax);
+    if (!packed) { split_wraw_h<8>(wa, rmax); split_wraw_h<8>(wb, rmax); }
     __syncthreads();
     const int e0 = __builtin_amdgcn_readfirstlane(srange[0]), e1 = __builtin_amdgcn_readfirstlane(srange[1]);
     if (e0 >= e1) { range_report(rmax); return; }
@@ -567,6 +568,7 @@ struct NodeArgs {
     const float* w0; const float* b0; const float* w1; const float* b1; const float* ln_w; const float* ln_b;
     const float* nw0; const float* nb0;          // next layer's first edge Linear [H][3H] and bias (PROJ)
     float* x_out; float* ps; float* pr; int n_nodes;
+    const void* pk0; const void* pk1; const void* pks; const void* pkr;   // packed planes of w0, w1, nw0[:, :H], nw0[:, H:2H], or null
 };
 
 template <bool PROJ>
@@ -674,7 +676,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_kernel(NodeArgs a) {
 // 32-node tile instead of 320 fp32 ones the kernel is bound by its HBM rows, not by the matrix pipe.
 constexpr int PKH2 = 2 * H + 8;     // ... of the 256-column [x | aggr] tile
 
-template <bool PROJ>
+template <bool PROJ, bool PACKED>
 __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short XAp[2 * TM * PKH2];   // [x | aggr] tile, 2 planes
     __shared__ __attribute__((aligned(16))) float Xf[tile_floats(H / 4)];        // x rows in fp32 (residual)
@@ -713,11 +715,18 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
     WPlanesH<8> wb, ws, wr;
     // all weight loads in flight before the first conversion (converted one set at a time, with this kernel's
     // register file full, the later sets load two values per round trip to memory)
-    load_wraw_h<16>(wa, a.w0, 2 * H, 0, 32 * w + j, h);
-    load_wraw_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
-    if constexpr (PROJ) {
-        load_wraw_h<8>(ws, a.nw0, 3 * H, 0, 32 * w + j, h);
-        load_wraw_h<8>(wr, a.nw0, 3 * H, H, 32 * w + j, h);
+    constexpr bool packed = PACKED;                  // weight planes prepared by pack_weights_kernel (range checked there)
+    if constexpr (packed) {
+        load_wpacked_h<16>(wa, a.pk0, w, lane);
+        load_wpacked_h<8>(wb, a.pk1, w, lane);
+        if constexpr (PROJ) { load_wpacked_h<8>(ws, a.pks, w, lane); load_wpacked_h<8>(wr, a.pkr, w, lane); }
+    } else {
+        load_wraw_h<16>(wa, a.w0, 2 * H, 0, 32 * w + j, h);
+        load_wraw_h<8>(wb, a.w1, H, 0, 32 * w + j, h);
+        if constexpr (PROJ) {
+            load_wraw_h<8>(ws, a.nw0, 3 * H, 0, 32 * w + j, h);
+            load_wraw_h<8>(wr, a.nw0, 3 * H, H, 32 * w + j, h);
+        }
     }
     float v5[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     if (t < H) { v5[0] = a.b0[t]; v5[1] = a.b1[t]; v5[2] = a.ln_w[t]; v5[3] = a.ln_b[t]; v5[4] = PROJ ? a.nb0[t] : 0.f; }
@@ -727,7 +736,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) vec[k][t] = v5[k];
     }
-    {
+    if constexpr (!packed) {
         float m = 0.f;
         split_wraw_h<16>(wa, m);
         split_wraw_h<8>(wb, m);
@@ -1177,6 +1186,29 @@ __global__ void edge_alpha_normalize_kernel(const int* __restrict__ rowptr, cons
     }
 }
 
+// ---- packed weight planes (fp16-split path): one workgroup per 128-row weight set, thread (wave, lane) writes the
+// register quads it will later hold, [wave][k-step][plane][lane], so that the consumers' loads are fully coalesced.
+struct PackSlice { const float* w; int ld, col0, ks; unsigned dst; };       // dst: offset into the block, in u32x4
+struct PackTable { PackSlice s[MGN_MAX_PACK_SLICES]; };
+
+__global__ __launch_bounds__(NT) void pack_weights_kernel(PackTable tab, u32x4* __restrict__ packed) {
+    const PackSlice s = tab.s[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
+    const float* row = s.w + (size_t)(32 * w + j) * s.ld + s.col0 + 8 * h;
+    u32x4* dst = packed + s.dst + (size_t)w * s.ks * 2 * 64 + lane;
+    float m = 0.f;
+    for (int c = 0; c < s.ks; ++c) {
+        const f32x4 lo4 = *(const f32x4*)(row + 16 * c) * W_SCALE, hi4 = *(const f32x4*)(row + 16 * c + 4) * W_SCALE;
+        track4(m, lo4); track4(m, hi4);
+        u32x2 a1, a2, b1, b2;
+        split2_pack4(lo4, a1, a2);
+        split2_pack4(hi4, b1, b2);
+        dst[(2 * c) * 64] = u32x4{a1[0], a1[1], b1[0], b1[1]};
+        dst[(2 * c + 1) * 64] = u32x4{a2[0], a2[1], b2[0], b2[1]};
+    }
+    range_report(m);
+}
+
 constexpr int SUM_BLOCKS_MAX = 1024;
 
 __global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* __restrict__ feat, long long rows,
@@ -1342,16 +1374,18 @@ extern "C" int mgn_mp_project(const float* x, const float* edge_w0, const float*
 
 static int launch_edge(const float* e_in, const float* ps, const float* pr, const int32_t* rowptr,
                        const int32_t* csr_sender, const int32_t* csr_recv, const mgn_mlp* m, const float* edge_weight,
-                       float* e_out, float* aggr, int64_t n_edges, int64_t n_nodes, void* stream, const char* name) {
+                       float* e_out, float* aggr, int64_t n_edges, int64_t n_nodes, void* stream, const char* name,
+                       const void* pk0 = nullptr, const void* pk1 = nullptr) {
     MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31) && n_nodes >= 0 && n_nodes < (1ll << 31), name);
     if (n_edges == 0) return 0;
     MGN_REQUIRE(e_in && ps && pr && rowptr && csr_sender && csr_recv && aggr && mlp_ok(m, true), name);
     // node rows are addressed with 32-bit element offsets
     MGN_REQUIRE(n_nodes * (int64_t)H < (1ll << 31), name);
     EdgeArgs a{e_in, ps, pr, rowptr, csr_sender, csr_recv, m->w0, m->w1, m->b1, m->ln_w, m->ln_b,
-               e_out, aggr, (int)n_edges, (int)n_nodes, edge_weight};
+               e_out, aggr, (int)n_edges, (int)n_nodes, edge_weight, nullptr, nullptr};
     const hipStream_t st = (hipStream_t)stream;
     if (matmul_mode() == 2) {
+        a.pk0 = pk0; a.pk1 = pk1;                    // the other matrix paths read the fp32 matrices
         const int g = grid_for((n_edges + TM - 1) / TM, 2);
         if (edge_weight) hipLaunchKernelGGL((mp_edge_h4_kernel<true>), dim3(g), dim3(NT), 0, st, a);
         else hipLaunchKernelGGL((mp_edge_h4_kernel<false>), dim3(g), dim3(NT), 0, st, a);
@@ -1383,6 +1417,15 @@ extern "C" int mgn_mp_edge_weighted(const float* e_in, const float* ps, const fl
                        "mgn_mp_edge_weighted");
 }
 
+extern "C" int mgn_mp_edge_packed(const float* e_in, const float* ps, const float* pr, const int32_t* rowptr,
+                                  const int32_t* csr_sender, const int32_t* csr_recv, const mgn_mlp* m,
+                                  const void* packed_w0e, const void* packed_w1, const float* edge_weight, float* e_out,
+                                  float* aggr, int64_t n_edges, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(packed_w0e && packed_w1, "mgn_mp_edge_packed");
+    return launch_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, m, edge_weight, e_out, aggr, n_edges, n_nodes, stream,
+                       "mgn_mp_edge_packed", packed_w0e, packed_w1);
+}
+
 extern "C" int mgn_edge_attention(const float* a_proj, const int32_t* rowptr, const int32_t* csr_sender,
                                   const int32_t* csr_recv, float* alpha, float* edge_weight, int64_t n_edges,
                                   int64_t n_nodes, void* stream) {
@@ -1400,16 +1443,23 @@ extern "C" int mgn_edge_attention(const float* a_proj, const int32_t* rowptr, co
 
 static int launch_node(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* m,
                        const float* next_w0, const float* next_b0, float* x_out, float* ps, float* pr,
-                       int64_t n_nodes, void* stream, const char* name) {
+                       int64_t n_nodes, void* stream, const char* name, const void* pk0 = nullptr,
+                       const void* pk1 = nullptr, const void* pks = nullptr, const void* pkr = nullptr) {
     MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), name);
     if (n_nodes == 0) return 0;
     MGN_REQUIRE(x && aggr && rowptr && x_out && mlp_ok(m, true), name);
     NodeArgs a{x, aggr, rowptr, m->w0, m->b0, m->w1, m->b1, m->ln_w, m->ln_b, next_w0, next_b0, x_out, ps, pr,
-               (int)n_nodes};
+               (int)n_nodes, nullptr, nullptr, nullptr, nullptr};
     const int g = grid_for((n_nodes + TM - 1) / TM, 1);
     if (matmul_mode() == 2) {
-        if (next_w0) hipLaunchKernelGGL((mp_node_h_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
-        else hipLaunchKernelGGL((mp_node_h_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+        a.pk0 = pk0; a.pk1 = pk1; a.pks = pks; a.pkr = pkr;      // the other matrix paths read the fp32 matrices
+        if (pk0) {
+            if (next_w0) hipLaunchKernelGGL((mp_node_h_kernel<true, true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((mp_node_h_kernel<false, true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+        } else {
+            if (next_w0) hipLaunchKernelGGL((mp_node_h_kernel<true, false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((mp_node_h_kernel<false, false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+        }
     } else {
         if (next_w0) hipLaunchKernelGGL((mp_node_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
         else hipLaunchKernelGGL((mp_node_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
@@ -1428,6 +1478,36 @@ extern "C" int mgn_mp_node_project(const float* x, const float* aggr, const int3
     MGN_REQUIRE(next_edge_w0 && next_edge_b0 && ps && pr, "mgn_mp_node_project");
     return launch_node(x, aggr, rowptr, m, next_edge_w0, next_edge_b0, x_out, ps, pr, n_nodes, stream,
                        "mgn_mp_node_project");
+}
+
+extern "C" int mgn_mp_node_packed(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* m,
+                                  const void* packed_w0, const void* packed_w1, const float* next_edge_w0,
+                                  const float* next_edge_b0, const void* packed_next_ws, const void* packed_next_wr,
+                                  float* x_out, float* ps, float* pr, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(packed_w0 && packed_w1, "mgn_mp_node_packed");
+    if (next_edge_w0) MGN_REQUIRE(next_edge_b0 && ps && pr && packed_next_ws && packed_next_wr, "mgn_mp_node_packed");
+    return launch_node(x, aggr, rowptr, m, next_edge_w0, next_edge_w0 ? next_edge_b0 : nullptr, x_out, ps, pr, n_nodes, stream,
+                       "mgn_mp_node_packed", packed_w0, packed_w1, packed_next_ws, packed_next_wr);
+}
+
+extern "C" int64_t mgn_packed_weight_bytes(int32_t k) {
+    return (k > 0 && k % 16 == 0) ? (int64_t)H * k * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int mgn_pack_weights(const mgn_weight_slice* slices, int32_t count, void* packed, void* stream) {
+    MGN_REQUIRE(count >= 0 && count <= MGN_MAX_PACK_SLICES && (count == 0 || (slices && packed)), "mgn_pack_weights");
+    if (count == 0) return 0;
+    PackTable tab;
+    unsigned off = 0;
+    for (int i = 0; i < count; ++i) {
+        const mgn_weight_slice& s = slices[i];
+        MGN_REQUIRE(s.w && s.k > 0 && s.k % 16 == 0 && s.k <= 1024 && s.col0 >= 0 && s.col0 % 4 == 0 && s.ld >= s.col0 + s.k &&
+                    s.ld % 4 == 0, "mgn_pack_weights");
+        tab.s[i] = PackSlice{s.w, s.ld, s.col0, s.k / 16, off};
+        off += (unsigned)(H * s.k / 4);              // u32x4 per set: 128 rows x k values, 4 bytes (two fp16) each
+    }
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(count), dim3(NT), 0, (hipStream_t)stream, tab, (u32x4*)packed);
+    return check_launch("mgn_pack_weights");
 }
 
 extern "C" int mgn_node_features(const float* world_pos, const float* mesh_pos, const float* phi,

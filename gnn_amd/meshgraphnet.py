@@ -138,7 +138,7 @@ class EdgeNodeMessagePassing(nn.Module):
         self.__dict__["_topo"] = TopologyCache()
 
     def step_csr(self, x, e_csr, topo: Topology, ps, pr, aggr, halo=None, projected=False, next_block=None,
-                 store_edges=True):
+                 store_edges=True, packed=None):
         """In place on ``x`` [N,H] and ``e_csr`` [E,H] (receiver-major edge order).
 
         ``projected``: ``ps``/``pr`` already hold this block's per-node projections (written by
@@ -146,7 +146,8 @@ class EdgeNodeMessagePassing(nn.Module):
         projections are then produced by this block's node kernel.  ``store_edges=False``: the
         updated edge latents are not written (last block of a stack).  With a ``halo`` plan only
         the first ``halo.num_owned`` rows of ``x`` are owned; the sender projections of the
-        remaining (halo) rows arrive from their owners."""
+        remaining (halo) rows arrive from their owners.  ``packed``: this block's (edge, node) entries of an
+        ``ops.PackedWeights`` refreshed in this call (single-GPU path only)."""
         ew, nw = self.edge_mlp.weights(), self.node_mlp.weights()
         n = x.shape[0] if halo is None else halo.num_owned
         e_out = e_csr if store_edges else None
@@ -167,11 +168,17 @@ class EdgeNodeMessagePassing(nn.Module):
         if halo is None and not ops.timing_enabled():       # the common path, without the timing contexts
             if not projected:
                 ops.mp_project(x, self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps, pr)
-            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, edge_weight=wts)
-            if next_block is None:
+            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, edge_weight=wts,
+                        packed=packed[0] if packed is not None else None)
+            nxt = next_block.edge_mlp._modules["0"]._parameters if next_block is not None else None
+            if packed is not None:
+                if nxt is None:
+                    ops.mp_node_packed(x, aggr, topo.rowptr, nw, packed[1], x)
+                else:
+                    ops.mp_node_packed(x, aggr, topo.rowptr, nw, packed[1], x, nxt["weight"].data, nxt["bias"].data, ps, pr)
+            elif nxt is None:
                 ops.mp_node(x, aggr, topo.rowptr, nw, x)
             else:
-                nxt = next_block.edge_mlp._modules["0"]._parameters
                 ops.mp_node_project(x, aggr, topo.rowptr, nw, nxt["weight"].data, nxt["bias"].data, x, ps, pr)
             return
         if not projected:
@@ -284,6 +291,12 @@ class EncodeProcessDecodeMultiScale(nn.Module):
     def _f32(t: torch.Tensor) -> torch.Tensor:
         return t.detach().to(torch.float32).contiguous()
 
+    def _packed(self, slot, blocks):
+        pk = self.__dict__.get(slot)
+        if pk is None:
+            pk = self.__dict__[slot] = ops.PackedWeights()
+        return pk.refresh(blocks)
+
     def _coarse_graph(self, mesh_pos):
         from .coarse import CoarseGraph
         start = self.__dict__.get("coarse_start")
@@ -364,16 +377,22 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             ops.encode(cw.edge_feat, ms_c, self.coarse_edge_encoder.weights(), cw.e)
             ops.gather_rows(ws.x, cg.first, cw.x)          # encoder output of the sampled nodes (:182)
         blocks = list(self.processors)
+        # prepared weight sets (one conversion launch per call: a snapshot of the parameters, so never stale)
+        use_pk = halo is None and not ops.timing_enabled() and ops.matmul_mode() == "f16x2"
+        pk = self._packed("_pk", blocks) if use_pk and blocks else None
         for i, proc in enumerate(blocks):
             last = i + 1 == len(blocks)           # nothing reads the edge latents after the last block
             proc.step_csr(ws.x, ws.e, topo, ws.ps, ws.pr, ws.aggr, halo, projected=i > 0,
-                          next_block=None if last else blocks[i + 1], store_edges=not last)
+                          next_block=None if last else blocks[i + 1], store_edges=not last,
+                          packed=(pk.edge[i], pk.node[i]) if pk is not None else None)
         if cg is not None:                        # :187-194
             cblocks = list(self.coarse_processors)
+            cpk = self._packed("_cpk", cblocks) if use_pk and cblocks else None
             for i, proc in enumerate(cblocks):
                 last = i + 1 == len(cblocks)
                 proc.step_csr(cw.x, cw.e, cg.topology, cw.ps, cw.pr, cw.aggr, None, projected=i > 0,
-                              next_block=None if last else cblocks[i + 1], store_edges=not last)
+                              next_block=None if last else cblocks[i + 1], store_edges=not last,
+                              packed=(cpk.edge[i], cpk.node[i]) if cpk is not None else None)
             cw.map_back.zero_()
             ops.scatter_rows(cw.x, cg.first, cw.map_back)
         return ws, topo

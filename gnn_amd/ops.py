@@ -214,10 +214,12 @@ def mp_project(x, w0, b0, ps, pr):
     _lib.check(rc, "mgn_mp_project")
 
 
-def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, aggr, node_range=None, edge_weight=None):
+def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, aggr, node_range=None, edge_weight=None,
+            packed=None):
     """``node_range = (n0, n1, edge_count)`` restricts the launch to the receivers n0 .. n1-1 and
     their ``edge_count`` in-edges (= rowptr[n1] - rowptr[n0], known to the caller on the host).
-    ``edge_weight`` [E] (CSR order): weights of the messages in the receivers' sums (attention)."""
+    ``edge_weight`` [E] (CSR order): weights of the messages in the receivers' sums (attention).
+    ``packed``: device addresses (w0[:, 2H:], w1) of the sets prepared by :class:`PackedWeights`."""
     ne, n = e_in.shape[0], ps.shape[0]
     if mlp.in_dim != 3 * H or mlp.out_dim != H:
         raise RuntimeError("mp_edge: edge MLP must be 3H -> H -> H")
@@ -235,9 +237,18 @@ def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, 
         n_sub = n1 - n0
         if n_sub == 0 or e_sub == 0:
             return
+    if edge_weight is not None and node_range is not None:
+        raise RuntimeError("mp_edge: weighted messages are not combined with receiver sub-ranges")
+    if packed is not None:
+        rc = _lib.lib().mgn_mp_edge_packed(
+            _dev(e_in, torch.float32, (ne, H), "e_in"), _dev(ps, torch.float32, (n, H), "ps"),
+            _dev(pr, torch.float32, (n, H), "pr"), rp, _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
+            _dev(csr_recv, torch.int32, (ne,), "csr_recv"), mlp.ref(), packed[0], packed[1],
+            _opt(edge_weight, torch.float32, (ne,), "edge_weight"),
+            _opt(e_out, torch.float32, (ne, H), "e_out"), _dev(aggr, torch.float32, (None, H), "aggr"), e_sub, n_sub, _stream())
+        _lib.check(rc, "mgn_mp_edge_packed")
+        return
     if edge_weight is not None:
-        if node_range is not None:
-            raise RuntimeError("mp_edge: weighted messages are not combined with receiver sub-ranges")
         rc = _lib.lib().mgn_mp_edge_weighted(
             _dev(e_in, torch.float32, (ne, H), "e_in"), _dev(ps, torch.float32, (n, H), "ps"),
             _dev(pr, torch.float32, (n, H), "pr"), rp, _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
@@ -284,6 +295,77 @@ def mp_node_project(x, aggr, rowptr, mlp: MlpWeights, next_w0, next_b0, x_out, p
         _dev(next_b0, torch.float32, (H,), "next edge b0"), _dev(x_out, torch.float32, (n, H), "x_out"),
         _dev(ps, torch.float32, (n, H), "ps"), _dev(pr, torch.float32, (n, H), "pr"), n, _stream())
     _lib.check(rc, "mgn_mp_node_project")
+
+
+def mp_node_packed(x, aggr, rowptr, mlp: MlpWeights, packed, x_out, next_w0=None, next_b0=None, ps=None, pr=None):
+    """:func:`mp_node` (``next_w0`` None) or :func:`mp_node_project` with prepared weight sets: ``packed`` = device
+    addresses (w0, w1, next ws, next wr) from :class:`PackedWeights`, the last two 0 without a next layer."""
+    n = x.shape[0]
+    if mlp.in_dim != 2 * H or mlp.out_dim != H:
+        raise RuntimeError("mp_node_packed: node MLP must be 2H -> H -> H")
+    proj = next_w0 is not None
+    rc = _lib.lib().mgn_mp_node_packed(
+        _dev(x, torch.float32, (n, H), "x"), _dev(aggr, torch.float32, (n, H), "aggr"),
+        _dev(rowptr, torch.int32, (n + 1,), "rowptr"), mlp.ref(), packed[0], packed[1],
+        _dev(next_w0, torch.float32, (H, 3 * H), "next edge w0") if proj else None,
+        _dev(next_b0, torch.float32, (H,), "next edge b0") if proj else None,
+        packed[2] if proj else None, packed[3] if proj else None, _dev(x_out, torch.float32, (n, H), "x_out"),
+        _dev(ps, torch.float32, (n, H), "ps") if proj else None, _dev(pr, torch.float32, (n, H), "pr") if proj else None,
+        n, _stream())
+    _lib.check(rc, "mgn_mp_node_packed")
+
+
+class PackedWeights:
+    """Weight sets of a stack of processor blocks in the layout the fp16-split kernels load fully coalesced
+    (``mgn_pack_weights``): per block the edge MLP's ``w0[:, 2H:]`` and ``w1``, the node MLP's ``w0`` and ``w1``, and the
+    sender / receiver thirds of the NEXT block's edge ``w0``.  ``refresh()`` converts all of them in one launch -- a
+    snapshot of the parameters, so it runs at the start of every call that uses the sets; the descriptor table and the
+    buffer are rebuilt only when a parameter tensor moves."""
+
+    def __init__(self):
+        self.key = None
+
+    def refresh(self, blocks):
+        params = []
+        for b in blocks:
+            em, nm = b.edge_mlp._modules, b.node_mlp._modules
+            params += [em["0"].weight.data, em["2"].weight.data, nm["0"].weight.data, nm["2"].weight.data]
+        key = tuple(p.data_ptr() for p in params)
+        if key != self.key:
+            nb = len(blocks)
+            if 6 * nb > _lib.MAX_PACK_SLICES:
+                raise RuntimeError(f"PackedWeights: at most {_lib.MAX_PACK_SLICES // 6} blocks per table")
+            sl, sizes = [], []
+            for i in range(nb):
+                e0, e1, n0, n1 = params[4 * i: 4 * i + 4]
+                for t in (e0, e1, n0, n1):
+                    _dev(t, torch.float32, (H, None), "processor weight")
+                sets = [(e0, 2 * H, H), (e1, 0, H), (n0, 0, 2 * H), (n1, 0, H)]
+                if i + 1 < nb:
+                    nxt = params[4 * (i + 1)]
+                    sets += [(nxt, 0, H), (nxt, H, H)]
+                for t, col0, k in sets:
+                    sl.append(_lib.MgnWeightSlice(t.data_ptr(), t.shape[1], col0, k, 0))
+                    sizes.append(int(_lib.lib().mgn_packed_weight_bytes(k)))
+            self.table = (_lib.MgnWeightSlice * len(sl))(*sl)
+            self.count = len(sl)
+            self.buf = torch.empty(sum(sizes), dtype=torch.uint8, device=params[0].device)
+            base, offs = self.buf.data_ptr(), [0]
+            for sz in sizes:
+                offs.append(offs[-1] + sz)
+            self.edge, self.node = [], []
+            j = 0
+            for i in range(nb):
+                a = [C.c_void_p(base + offs[j + q]) for q in range(4)]
+                nx = [C.c_void_p(base + offs[j + 4]), C.c_void_p(base + offs[j + 5])] if i + 1 < nb else [None, None]
+                self.edge.append((a[0], a[1]))
+                self.node.append((a[2], a[3], nx[0], nx[1]))
+                j += 6 if i + 1 < nb else 4
+            self.keep = params                      # the table holds raw addresses of these tensors
+            self.key = key
+        rc = _lib.lib().mgn_pack_weights(self.table, self.count, C.c_void_p(self.buf.data_ptr()), _stream())
+        _lib.check(rc, "mgn_pack_weights")
+        return self
 
 
 # --------------------------------------------------------------------------- device: features etc.

@@ -14,13 +14,20 @@ import torch
 from .graph import MeshGraph, batch_graphs, unbatch_nodes
 
 
+GRAPH_AUTO_MAX_EDGES = 50_000
+
+
 def _wants_graph(model, first, use_graph):
-    """Graph replay is opt-in (``use_graph=True`` or ``MGN_ROLLOUT_GRAPH=1``): with the host-side cost
-    of a launch at a few microseconds, the eager sequence of a 561-node step (0.50 ms) is no slower
-    than replaying its captured graph (0.52 ms), and at 36k nodes replay is slower."""
+    """Graph replay: ``use_graph=True/False`` or ``MGN_ROLLOUT_GRAPH=1/0`` decide; left open, it is used for meshes
+    of at most 50 000 edges.  There a step's ~40 launches occupy the GPU for less time (0.35 ms at 561 nodes) than
+    the host needs to issue them (0.45 ms), and replaying the captured step takes 0.39 ms; at 200 000 edges the
+    host keeps ahead of the GPU and replay is the slower of the two.  Results are bit-identical either way.  Not
+    with a partitioned model, and not with the coarse branch (its graph is redrawn per call)."""
     if use_graph is None:
-        use_graph = os.environ.get("MGN_ROLLOUT_GRAPH", "0") not in ("", "0")
-    return bool(use_graph) and model.__dict__.get("halo") is None and torch.device(model.device).type == "cuda"
+        env = os.environ.get("MGN_ROLLOUT_GRAPH", "")
+        use_graph = first["edge_index"].shape[1] <= GRAPH_AUTO_MAX_EDGES if env == "" else env != "0"
+    return (bool(use_graph) and model.__dict__.get("halo") is None and torch.device(model.device).type == "cuda"
+            and getattr(model, "sample_ratio", 0.0) == 0)
 
 
 class _StepGraph:
@@ -91,8 +98,8 @@ class _StepGraph:
 def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
     """``reorder``: None, or "rcm" / "morton" to renumber the nodes for locality before the
     first step (meshes whose ids do not follow the geometry); every returned tensor stays in
-    the order of ``data``.  ``use_graph``: replay each step as one captured HIP graph (default off;
-    ``MGN_ROLLOUT_GRAPH=1`` turns it on)."""
+    the order of ``data``.  ``use_graph``: replay each step as one captured HIP graph (default: for small
+    meshes, see :func:`_wants_graph`; ``MGN_ROLLOUT_GRAPH=0/1`` overrides)."""
     if reorder is not None:
         return _rollout_reordered(model, data, progress, reorder, use_graph)
     device = model.device

@@ -34,6 +34,7 @@ extern "C" {
 #define MGN_ABI_VERSION 1
 #define MGN_MAX_FEAT 16      /* widest raw feature row an encoder accepts            */
 #define MGN_MAX_DEC_OUT 32   /* widest decoder output (node_out_dim * time_dim)      */
+#define MGN_MAX_PACK_SLICES 112   /* weight sets per mgn_pack_weights call           */
 
 #define MGN_E_ARG   (-1)     /* bad argument (null pointer, size out of range, ...)  */
 #define MGN_E_RANGE (-2)     /* index outside [0, N)                                 */
@@ -154,6 +155,46 @@ int mgn_mp_node(const float* x /*[N][H]*/, const float* aggr /*[N][H]*/, const i
 int mgn_mp_node_project(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* node_mlp,
                         const float* next_edge_w0, const float* next_edge_b0,
                         float* x_out, float* ps, float* pr, int64_t n_nodes, void* stream);
+
+/* ---- prepared weights (optional; same results bit for bit) -------------------------
+ * The processor kernels keep their weights in registers for a whole launch and convert them from the
+ * row-major fp32 matrices when a workgroup starts (core/meshgraphnet.py:64-78 holds them as nn.Linear
+ * parameters).  On meshes of a few hundred nodes (one tile per workgroup) that start is most of the launch:
+ * mgn_pack_weights converts any number of weight sets in one launch into the layout the kernels load fully
+ * coalesced, and the *_packed entry points take those blocks beside the mgn_mlp.  One set = the 128 rows x k
+ * columns [col0, col0 + k) of a row-major matrix with row stride ld (k a multiple of 16, col0 and ld multiples
+ * of 4); it occupies mgn_packed_weight_bytes(k) = 512 * k bytes, set i at the sum of the sizes before it.
+ * The blocks are valid for the matrix path that was current when they were packed, hold a snapshot of the
+ * weights (pack again after an optimiser step), and are ignored by the two paths that read fp32 matrices.
+ * The range guard of the fp16-split path (mgn_range_check) sees the weights in mgn_pack_weights.           */
+typedef struct mgn_weight_slice {
+    const float* w;    /* row-major matrix, 128 rows */
+    int32_t ld;        /* row stride in floats       */
+    int32_t col0;      /* first column of the set    */
+    int32_t k;         /* columns of the set         */
+    int32_t reserved;
+} mgn_weight_slice;
+
+int64_t mgn_packed_weight_bytes(int32_t k);
+int mgn_pack_weights(const mgn_weight_slice* slices /*host array*/, int32_t count /* <= MGN_MAX_PACK_SLICES */,
+                     void* packed /*device*/, void* stream);
+
+/* mgn_mp_edge / mgn_mp_edge_weighted (edge_weight NULL = unweighted) with the packed sets of
+ * edge_mlp->w0[:, 2H:3H] (k = 128) and edge_mlp->w1 (k = 128); edge_mlp still supplies b1, ln_w, ln_b and the
+ * matrices for the paths that ignore the packed sets. */
+int mgn_mp_edge_packed(const float* e_in, const float* ps, const float* pr,
+                       const int32_t* rowptr, const int32_t* csr_sender, const int32_t* csr_recv,
+                       const mgn_mlp* edge_mlp, const void* packed_w0e, const void* packed_w1,
+                       const float* edge_weight /*[E] or NULL*/, float* e_out, float* aggr,
+                       int64_t n_edges, int64_t n_nodes, void* stream);
+
+/* mgn_mp_node (next_edge_w0 NULL) / mgn_mp_node_project with the packed sets of node_mlp->w0 (k = 256),
+ * node_mlp->w1 (k = 128) and, with a next layer, next_edge_w0[:, 0:H] and next_edge_w0[:, H:2H] (k = 128 each). */
+int mgn_mp_node_packed(const float* x, const float* aggr, const int32_t* rowptr, const mgn_mlp* node_mlp,
+                       const void* packed_w0, const void* packed_w1,
+                       const float* next_edge_w0 /*or NULL*/, const float* next_edge_b0,
+                       const void* packed_next_ws, const void* packed_next_wr,
+                       float* x_out, float* ps, float* pr, int64_t n_nodes, void* stream);
 
 /* ---- device side: features, normaliser, encoder, decoder --------------------------
  * _build_node_features (core/meshgraphnet.py:212-225): feat row =

@@ -123,3 +123,64 @@ def test_edge_update_in_receiver_subranges():
     before = ef.clone()
     ops.mp_edge(ef, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, None, a3)
     assert torch.equal(a3, a1) and torch.equal(ef, before)
+
+
+@pytest.mark.parametrize("nx,ny,nblocks", [(32, 16, 3), (5, 4, 1), (120, 70, 2)])
+def test_prepared_weight_sets_change_nothing(nx, ny, nblocks, matmul_mode):
+    """A stack of blocks run through the *_packed entry points (weight sets converted once by mgn_pack_weights) equals
+    the plain entry points bit for bit, in the fp16-split path that uses the sets and in the two that ignore them;
+    sets are a snapshot: after a weight changes, a refresh is needed and sufficient."""
+    from gnn_amd import ops
+    from gnn_amd.graph import Topology
+    cfg = O.OracleConfig(process_steps=nblocks)
+    sd = O.init_state_dict(cfg, 11)
+    blocks = [_model_layer(sd, i, DEV) for i in range(nblocks)]
+    g = O.synthetic_graph(nx, ny, seed=2)
+    n, ne = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
+    topo = Topology(g["edge_index"], n, DEV)
+    gen = torch.Generator().manual_seed(3)
+    x0, e0 = torch.randn(n, 128, generator=gen).to(DEV), torch.randn(ne, 128, generator=gen).to(DEV)
+
+    def run(pk):
+        x, e = x0.clone(), e0.clone()
+        ps, pr, aggr = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        for i, b in enumerate(blocks):
+            last = i + 1 == nblocks
+            b.step_csr(x, e, topo, ps, pr, aggr, projected=i > 0, next_block=None if last else blocks[i + 1],
+                       packed=(pk.edge[i], pk.node[i]) if pk is not None else None)
+        return x, e
+
+    plain = run(None)
+    pk = ops.PackedWeights().refresh(blocks)
+    assert pk.count == 6 * nblocks - 2
+    packed = run(pk)
+    assert torch.equal(plain[0], packed[0]) and torch.equal(plain[1], packed[1])
+    with torch.no_grad():
+        blocks[0].edge_mlp[2].weight.mul_(1.5)
+        blocks[-1].node_mlp[0].weight.add_(0.01)
+    plain2 = run(None)
+    assert not torch.equal(plain2[0], plain[0])
+    packed2 = run(pk.refresh(blocks))
+    assert torch.equal(plain2[0], packed2[0]) and torch.equal(plain2[1], packed2[1])
+
+
+def test_pack_weights_argument_checks_and_range_guard():
+    import ctypes as C
+    from gnn_amd import _lib, ops
+    w = torch.randn(128, 384, device=DEV)
+    buf = torch.empty(128 * 128 * 4, dtype=torch.uint8, device=DEV)
+    lib = _lib.lib()
+    assert lib.mgn_packed_weight_bytes(128) == 65536 and lib.mgn_packed_weight_bytes(256) == 131072
+    assert lib.mgn_packed_weight_bytes(100) == 0
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for bad in (_lib.MgnWeightSlice(w.data_ptr(), 384, 300, 128, 0),      # runs past the row
+                _lib.MgnWeightSlice(w.data_ptr(), 384, 0, 100, 0),        # k not a multiple of 16
+                _lib.MgnWeightSlice(None, 384, 0, 128, 0)):
+        assert lib.mgn_pack_weights((_lib.MgnWeightSlice * 1)(bad), 1, C.c_void_p(buf.data_ptr()), stream) == -1
+    assert lib.mgn_pack_weights(None, 113, C.c_void_p(buf.data_ptr()), stream) == -1
+    if ops.matmul_mode() == "f16x2":
+        ops.range_check(reset=True)
+        w[5, 200] = 600.0                                                   # 600 * 128 is beyond fp16
+        ok = _lib.MgnWeightSlice(w.data_ptr(), 384, 128, 128, 0)
+        assert lib.mgn_pack_weights((_lib.MgnWeightSlice * 1)(ok), 1, C.c_void_p(buf.data_ptr()), stream) == 0
+        assert ops.range_check(reset=True) is True
