@@ -295,7 +295,31 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         pk = self.__dict__.get(slot)
         if pk is None:
             pk = self.__dict__[slot] = ops.PackedWeights()
+        frozen = self.__dict__.get("_weights_frozen")
+        if frozen is not None:                  # inside constant_weights(): convert once, on first use
+            if slot not in frozen:
+                pk.refresh(blocks)
+                frozen.add(slot)
+            return pk
         return pk.refresh(blocks)
+
+    def constant_weights(self):
+        """Context manager for a sequence of ``predict`` / ``forward`` calls during which the caller does not change
+        the parameters (a rollout): the prepared weight sets are converted on the first call only instead of on
+        every call."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            outer = self.__dict__.get("_weights_frozen")
+            if outer is None:
+                self.__dict__["_weights_frozen"] = set()
+            try:
+                yield self
+            finally:
+                if outer is None:
+                    self.__dict__["_weights_frozen"] = None
+        return scope()
 
     def _coarse_graph(self, mesh_pos):
         from .coarse import CoarseGraph

@@ -106,7 +106,9 @@ def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
     time_dim = model.time_dim
     n_frames = len(data)
     first = data[0]
-    with torch.no_grad():
+    import contextlib
+    frozen = model.constant_weights() if hasattr(model, "constant_weights") else contextlib.nullcontext()
+    with torch.no_grad(), frozen:
         static = MeshGraph(mesh_pos=first["mesh_pos"], node_type=first["node_type"], mat_param=first["mat_param"],
                            edge_index=first["edge_index"]).to(device)
         # swelling schedule [T + time_dim, N], zero past the end (rollout.py:17-26)

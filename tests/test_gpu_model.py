@@ -449,3 +449,25 @@ def test_100k_node_mesh_15_steps_8_batched_trajectories():
     cur = torch.cat([gc["world_pos"], gc["phi"]], -1)[far]
     assert rel_l2(got, ref[0][far]) < TOL
     assert rel_l2(got - cur, ref[0][far] - cur) < 5 * TOL, rel_l2(got - cur, ref[0][far] - cur)
+
+
+def test_constant_weights_scope():
+    """Inside ``model.constant_weights()`` the prepared weight sets are converted once (what ``rollout`` uses);
+    calls give the same bits as outside, and a parameter change made after the scope is seen by the next call."""
+    cfg = O.OracleConfig(process_steps=3)
+    sd = O.init_state_dict(cfg, 2)
+    model = build_model(cfg, sd)
+    g = graph_to(O.synthetic_graph(20, 11, seed=8), DEV)
+    model.predict(g)
+    for nrm in (model.node_features_normalizer, model.edge_features_normalizer):
+        nrm._max_accumulations = 0
+    ref = model.predict(g)
+    with model.constant_weights():
+        a, b = model.predict(g), model.predict(g)
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    with torch.no_grad():
+        model.processors[1].edge_mlp[2].weight.mul_(1.25)
+    changed = model.predict(g)
+    assert not torch.equal(changed, ref)
+    with model.constant_weights():
+        assert torch.equal(model.predict(g), changed)
