@@ -324,7 +324,12 @@ def main():
                                "matrix_pipe_frac": products * ach / pipe_peak,
                                "matrix_pipe_busy_measured": pmc_record().get("mfma_busy_frac") if pmc_record().get("kernel") == kernel else None,
                                "counters": {k: pmc_record().get(k) for k in ("wave_cycle_shares", "l2_hit_rate", "clock_GHz_under_profiler", "source")} if pmc_record().get("kernel") == kernel else None,
-                               "floor_ms": {"hbm": t_floor_hbm * 1e3, "mfma": t_floor_mfma * 1e3}}
+                               "floor_ms": {"hbm": t_floor_hbm * 1e3, "mfma": t_floor_mfma * 1e3},
+                               # the counter traffic (e rows, node-side gathers and sums included) over this launch time,
+                               # beside what plain streaming kernels reach on this GPU (scripts/micro/hbm_stream.hip, 3 GiB
+                               # arrays: copy 4.7-5.4, 2 reads + 1 write 4.7-5.3 TB/s)
+                               "moved_GBs": (traffic / t_edge / 1e9) if traffic else None,
+                               "streaming_kernel_GBs_measured": [4700.0, 5400.0]}
             # one MP step = everything the processor launches for one layer; the projection of
             # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
             n_layers = args.steps * args.mp_steps
