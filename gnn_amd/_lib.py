@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgn_hip.so")
+LIB_PATH = os.environ.get("MGN_LIB_PATH") or os.path.join(_HERE, "libmgn_hip.so")   # override: kernel experiments
 ABI_VERSION = 1
 H = 128
 MAX_FEAT = 16

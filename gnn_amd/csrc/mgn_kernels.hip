@@ -812,6 +812,12 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         __syncthreads();                                             // (4) new x complete
         STAMP(10);
         if constexpr (PROJ) {
+            // the new rows leave before the projections: their stores queue up behind the matrix instructions
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
+                if (row < nvalid) *(f32x4*)(a.x_out + (size_t)(base + row) * H + 4 * sq) = *(const f32x4*)(Os + toff(row, sq, H / 4));
+            }
             f32x16 as = zero16(), ar = zero16();
             wave_gemm_h2<0, 8, 8>(Np, PL, PKH, 0, ws, wr, j, h, as, ar);
 #pragma unroll
@@ -828,7 +834,7 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
             const int row = srow + 8 * it;
             if (row < nvalid) {
                 const size_t o = (size_t)(base + row) * H + 4 * sq;
-                *(f32x4*)(a.x_out + o) = *(const f32x4*)(Os + toff(row, sq, H / 4));
+                if constexpr (!PROJ) *(f32x4*)(a.x_out + o) = *(const f32x4*)(Os + toff(row, sq, H / 4));
                 if constexpr (PROJ) {
                     *(f32x4*)(a.ps + o) = *(const f32x4*)(Ps + toff(row, sq, H / 4));
                     *(f32x4*)(a.pr + o) = *(const f32x4*)(Pr + toff(row, sq, H / 4));
