@@ -402,7 +402,8 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             ops.gather_rows(ws.x, cg.first, cw.x)          # encoder output of the sampled nodes (:182)
         blocks = list(self.processors)
         # prepared weight sets (one conversion launch per call: a snapshot of the parameters, so never stale)
-        use_pk = halo is None and not ops.timing_enabled() and ops.matmul_mode() == "f16x2"
+        use_pk = (halo is None and not ops.timing_enabled() and ops.matmul_mode() == "f16x2"
+                  and os.environ.get("MGN_PACKED_WEIGHTS", "1") != "0")
         pk = self._packed("_pk", blocks) if use_pk and blocks else None
         for i, proc in enumerate(blocks):
             last = i + 1 == len(blocks)           # nothing reads the edge latents after the last block
