@@ -181,6 +181,37 @@ def train_object(args, device):
     return out
 
 
+def other_configs(device):
+    """The two single-GPU configurations of the baseline that the headline workload does not cover, each a few hundred
+    milliseconds: the bending-mesh rollout (33 x 17 nodes, 10 blocks, 200 frames) and the 100k-node mesh with 15 blocks
+    advanced as 8 block-diagonal trajectories (`scripts/bench_configs.py` prints the same figures)."""
+    import gnn_amd
+    from gnn_amd.rollout import rollout
+    out = {}
+    torch.manual_seed(0)
+    m = make_model(10, device).eval()
+    frames = gnn_amd.synthetic_frames(32, 16, n_frames=200, seed=0, lx=0.08, ly=0.01)
+    rollout(m, frames[:20])
+    torch.cuda.synchronize(device); t0 = time.perf_counter()
+    rollout(m, frames)
+    torch.cuda.synchronize(device); dt = time.perf_counter() - t0
+    out["bending_rollout"] = {"workload": "33x17-node bending mesh, 10 MP steps, 200-frame rollout (upload, loop, RMSE)",
+                              "rollout_steps_per_s": 200 / dt, "ms_per_step": dt / 200 * 1e3,
+                              "edge_updates_per_s": 3168 * 10 * 200 / dt}
+    g = gnn_amd.batch_graphs([gnn_amd.synthetic_frames(316, 316, seed=0)[0]] * 8).to(device)
+    m = make_model(15, device).eval()
+    e = g["edge_index"].shape[1]
+    for _ in range(2):
+        m.predict(g)
+    torch.cuda.synchronize(device); t0 = time.perf_counter()
+    for _ in range(4):
+        m.predict(g)
+    torch.cuda.synchronize(device); dt = (time.perf_counter() - t0) / 4
+    out["batched_100k_x8"] = {"workload": "317x317-node mesh, 15 MP steps, 8 trajectories as one block-diagonal graph",
+                              "ms_per_step": dt * 1e3, "trajectory_steps_per_s": 8 / dt, "edge_updates_per_s": e * 15 / dt}
+    return out
+
+
 def cpu_baseline(g, mp_steps, reps):
     """The CPU oracle (a port of the reference's processor block) on this host's cores: one
     message-passing layer on the full mesh, the same inputs shape as the GPU run."""
@@ -346,6 +377,7 @@ def main():
             del model, g
             torch.cuda.empty_cache()
             out["train"] = train_object(args, device)
+            out["other_configs"] = other_configs(device)
         print(json.dumps(out), flush=True)
     if world_size > 1:
         import torch.distributed as dist
