@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--cpu-reps", type=int, default=2, help="timed repetitions of the CPU baseline layer (0 = skip)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="N > 1: partition the fixed grid x grid mesh (strong) or keep grid x grid nodes per GPU (weak)")
+    ap.add_argument("--reorder", choices=("none", "morton", "rcm"), default="none",
+                    help="N = 1 experiment: renumber the mesh nodes before the run (the headline workload is row-major: none)")
     ap.add_argument("--train-steps", type=int, default=3, help="N = 1: timed training steps for the `train` object (0 = skip)")
     ap.add_argument("--train-grid", type=int, default=500)
     ap.add_argument("--train-mp-steps", type=int, default=10)
@@ -108,13 +110,16 @@ def make_model(mp_steps, device):
                                          time_dim=1, device=device).to(device)
 
 
-def build_problem(side, mp_steps, device, world_size, rank, scaling):
+def build_problem(side, mp_steps, device, world_size, rank, scaling, reorder="none"):
     """(model, full frame or None, this rank's frame on the device, plan, global nodes, global edges, mesh rows)."""
     import gnn_amd
     from gnn_amd import partition
     model = make_model(mp_steps, device).eval()
     if world_size == 1:
         g = gnn_amd.synthetic_frames(side - 1, side - 1, n_frames=1, seed=0)[0]
+        if reorder != "none":               # experiment: the same mesh with its nodes renumbered for locality
+            from gnn_amd import reorder as R
+            g = R.permute_frame(g, R.node_order(g, reorder))
         return model, g, g.to(device), None, g["mesh_pos"].shape[0], g["edge_index"].shape[1], side
     # every rank builds its own strip (plus one mesh row on either side), never the whole mesh
     rows = side if scaling == "strong" else side * world_size
@@ -260,7 +265,7 @@ def main():
             dist.init_process_group(backend)
 
     from gnn_amd import ops
-    model, g_full, g, plan, n, e, rows = build_problem(args.grid, args.mp_steps, device, world_size, rank, args.scaling)
+    model, g_full, g, plan, n, e, rows = build_problem(args.grid, args.mp_steps, device, world_size, rank, args.scaling, args.reorder)
 
     def step(state):
         pred = model.predict(state, check_range=False)      # range flag read once, after the timed region
@@ -312,7 +317,7 @@ def main():
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (2-term fp16 split operands, fp32 accumulate)" if os.environ.get("MGN_MATMUL", "f16x2") == "f16x2" else "f32", "data": "synthetic",
             "config": {"workload": f"synthetic {args.grid}x{rows}-node triangle mesh, one rollout step (predict) "
                                    f"= {args.mp_steps} MP steps + encoder + decoder + integrator",
-                       "nodes": n, "edges": e, "mp_steps": args.mp_steps, "latent": 128,
+                       "nodes": n, "edges": e, "mp_steps": args.mp_steps, "latent": 128, "node_order": "row-major" if args.reorder == "none" else args.reorder,
                        "parallelism": (f"node-range partition x{world_size} ({args.grid}x{rows // world_size} nodes per GPU, halo "
                                        "exchange of the sender projections per MP step)") if world_size > 1 else "single GPU"},
             "edge_updates_per_s_per_gpu": e * args.mp_steps * args.steps / dt / world_size,
