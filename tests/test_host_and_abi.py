@@ -149,3 +149,27 @@ def test_batch_graphs_block_diagonal():
     b2["mat_param"] = b2["mat_param"] * 2
     with pytest.raises(ValueError):
         gnn_amd.batch_graphs([a, b2])
+
+
+def test_size_limits_are_rejected_on_the_host():
+    """Maximum sizes: arguments beyond what the kernels address are refused before anything is launched (no GPU
+    needed: the pointers are never followed).  Node rows are addressed with 32-bit element offsets (n * 128 < 2^31),
+    edge and node counts are 31-bit, decoder outputs are at most 32 wide, feature rows at most 16."""
+    import ctypes as C
+    from gnn_amd import _lib
+    lib = _lib.lib()
+    p = C.c_void_p(0x1000)
+    mlp = _lib.MgnMlp(0x1000, 0x1000, 0x1000, 0x1000, 0x1000, 0x1000)
+    n_max = (1 << 31) // 128
+    assert lib.mgn_mp_edge(p, p, p, p, p, p, C.byref(mlp), p, p, 10, n_max, None) == -1
+    assert b"mgn_mp_edge" in lib.mgn_last_error()
+    assert lib.mgn_mp_edge(p, p, p, p, p, p, C.byref(mlp), p, p, 1 << 31, 10, None) == -1
+    assert lib.mgn_mp_node(p, p, p, C.byref(mlp), p, 1 << 31, None) == -1
+    assert lib.mgn_mp_edge(p, p, p, p, p, p, C.byref(mlp), p, p, -1, 10, None) == -1
+    assert lib.mgn_mp_edge(None, p, p, p, p, p, C.byref(mlp), p, p, 10, 10, None) == -1
+    assert lib.mgn_feature_sums(p, 10, 17, p, p, None) == -1                      # wider than MGN_MAX_FEAT
+    assert lib.mgn_encode(p, 17, p, C.byref(mlp), p, 10, None) == -1
+    assert lib.mgn_decode(p, C.byref(mlp), 11, 3, p, None, None, None, None, None, 10, None) == -1   # 33 outputs
+    # empty inputs are not an error and launch nothing
+    assert lib.mgn_mp_edge(None, None, None, None, None, None, C.byref(mlp), None, None, 0, 0, None) == 0
+    assert lib.mgn_mp_node(None, None, None, C.byref(mlp), None, 0, None) == 0
