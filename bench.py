@@ -186,7 +186,7 @@ def train_object(args, device):
     return out
 
 
-def other_configs(device):
+def other_configs(device, cpu=True):
     """The two single-GPU configurations of the baseline that the headline workload does not cover, each a few hundred
     milliseconds: the bending-mesh rollout (33 x 17 nodes, 10 blocks, 200 frames) and the 100k-node mesh with 15 blocks
     advanced as 8 block-diagonal trajectories (`scripts/bench_configs.py` prints the same figures)."""
@@ -203,6 +203,23 @@ def other_configs(device):
     out["bending_rollout"] = {"workload": "33x17-node bending mesh, 10 MP steps, 200-frame rollout (upload, loop, RMSE)",
                               "rollout_steps_per_s": 200 / dt, "ms_per_step": dt / 200 * 1e3,
                               "edge_updates_per_s": 3168 * 10 * 200 / dt}
+    if cpu:
+        # the same step on the host cores: the CPU oracle's predict on this mesh (20 timed calls after 2 warm-up calls)
+        import oracle as O
+        cfg = O.OracleConfig(process_steps=10)
+        sd, norms = O.init_state_dict(cfg, 0), O.make_norms(cfg)
+        fr = {k: frames[0][k] for k in ("world_pos", "mesh_pos", "phi", "node_type", "mat_param", "edge_index")}
+        fr["swelling_phi"] = torch.stack([frames[0]["swelling_phi"], frames[1]["swelling_phi"]]).T.contiguous()   # window t, t+1
+        with torch.no_grad():
+            for _ in range(2):
+                O.predict(sd, cfg, norms, fr)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                O.predict(sd, cfg, norms, fr)
+            dtc = (time.perf_counter() - t0) / 20
+        out["bending_rollout"]["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "rollout steps/s", "cores": torch.get_num_threads(),
+                                                  "kind": "port", "sample": "20 predict calls of the CPU oracle on the same mesh",
+                                                  "ms_per_step": dtc * 1e3}
     g = gnn_amd.batch_graphs([gnn_amd.synthetic_frames(316, 316, seed=0)[0]] * 8).to(device)
     m = make_model(15, device).eval()
     e = g["edge_index"].shape[1]
@@ -382,7 +399,7 @@ def main():
             del model, g
             torch.cuda.empty_cache()
             out["train"] = train_object(args, device)
-            out["other_configs"] = other_configs(device)
+            out["other_configs"] = other_configs(device, cpu=args.cpu_reps > 0)
         print(json.dumps(out), flush=True)
     if world_size > 1:
         import torch.distributed as dist
