@@ -1257,7 +1257,15 @@ __global__ __launch_bounds__(NT) void feature_sums_final_kernel(const double* __
     __shared__ double sh[8][2 * MGN_MAX_FEAT];
     const int col = threadIdx.x & (2 * MGN_MAX_FEAT - 1), c = threadIdx.x / (2 * MGN_MAX_FEAT);
     double acc = 0.0;
-    for (int b = c; b < nblocks; b += 8) acc += partial[(size_t)b * 2 * MGN_MAX_FEAT + col];
+    int b = c;
+    for (; b + 56 < nblocks; b += 64) {              // eight loads in flight, added in the order of the plain loop
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 8 * u) * 2 * MGN_MAX_FEAT + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nblocks; b += 8) acc += partial[(size_t)b * 2 * MGN_MAX_FEAT + col];
     sh[c][col] = acc;
     __syncthreads();
     if (threadIdx.x < 2 * F) {
