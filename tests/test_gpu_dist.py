@@ -1,6 +1,6 @@
 """GPU: the mesh-partitioned path through torch.distributed with real processes (tests/dist_worker.py under
-torch.distributed.run): once over gloo with both ranks on one GPU (runs everywhere), once over RCCL with one
-GPU per rank (needs two GPUs).  The stitched two-rank rollout, the loss and all 136 gradients must equal the
+torch.distributed.run) over gloo with both ranks on one GPU (runs everywhere); the same over RCCL with one GPU
+per rank is tests/test_zy_rccl.py (needs two GPUs).  The stitched two-rank rollout, the loss and all 136 gradients must equal the
 single-GPU run of the same mesh."""
 import json
 import os
@@ -39,9 +39,3 @@ def _check(r):
 
 def test_two_processes_gloo_transport_one_gpu():
     _check(_run("gloo"))
-
-
-def test_two_processes_rccl_one_gpu_each():
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs (one rank per GPU over RCCL)")
-    _check(_run("nccl"))
