@@ -29,35 +29,44 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        fast = self.__dict__.setdefault("_fast", {})
         for gi, group in enumerate(self.param_groups):
             params = [p for p in group["params"] if p.grad is not None]
             if not params:
                 continue
             dev = params[0].device
-            for p in params:
-                st = self.state[p]
-                if st and torch.is_tensor(st["step"]):       # a state_dict written by torch.optim.Adam keeps the count as a tensor
-                    st["step"] = int(st["step"].item())
-                if not st:
-                    if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
-                        raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU")
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            # the per-parameter state dictionaries, looked up once (hashing a tensor costs more than the rest of this
+            # loop); load_state_dict / __setstate__ drop the list, and the identity check catches a replaced entry list
+            hit = fast.get(gi)
+            if hit is None or len(hit[0]) != len(params) or any(a is not b for a, b in zip(hit[0], params)):
+                states = []
+                for p in params:
+                    st = self.state[p]
+                    if st and torch.is_tensor(st["step"]):       # a state_dict written by torch.optim.Adam keeps the count as a tensor
+                        st["step"] = int(st["step"].item())
+                    if not st:
+                        if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                            raise RuntimeError("FusedAdam: parameters must be contiguous fp32 tensors on the GPU")
+                        st["step"] = 0
+                        st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                        st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    states.append(st)
+                hit = fast[gi] = (list(params), states)
+            states = hit[1]
+            for st in states:
                 st["step"] += 1
-            step = self.state[params[0]]["step"]
+            step = states[0]["step"]
             # the pointer table is rebuilt and uploaded only when an address changed (gradients are
             # usually re-allocated at the same addresses step after step)
             # (load_state_dict / a replaced state entry installs new moment tensors: their addresses are part of the key)
             key = (tuple(p.grad.data_ptr() for p in params) + tuple(p.data_ptr() for p in params)
-                   + tuple(self.state[p]["exp_avg"].data_ptr() for p in params)
-                   + tuple(self.state[p]["exp_avg_sq"].data_ptr() for p in params))
+                   + tuple(st["exp_avg"].data_ptr() for st in states) + tuple(st["exp_avg_sq"].data_ptr() for st in states))
             cache = self.__dict__.setdefault("_tables", {})
             hit = cache.get(gi)
             if hit is None or hit[0] != key:
                 rows, keep = [], []
-                for p in params:
-                    g, st = p.grad, self.state[p]
+                for p, st in zip(params, states):
+                    g = p.grad
                     if g.is_sparse or g.dtype != torch.float32 or g.device != p.device or p.device != dev:
                         raise RuntimeError("FusedAdam: gradients must be dense fp32 tensors on the parameters' device")
                     if st["step"] != step:
@@ -80,3 +89,11 @@ class FusedAdam(torch.optim.Optimizer):
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream))
             _lib.check(rc, "mgn_adam_step")
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self.__dict__["_fast"] = {}                  # new state dictionaries
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self.__dict__["_fast"] = {}
