@@ -916,6 +916,21 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamEntry* __restrict__ 
     }
 }
 
+// The same update with its six scalars in device memory (a captured launch sequence cannot take new kernel
+// arguments from step to step): hyper = {lr / (1 - b1^t), 1 / sqrt(1 - b2^t), b1, b2, eps, weight decay}.
+__global__ __launch_bounds__(NT) void adam_dev_kernel(const AdamEntry* __restrict__ table, const float* __restrict__ hyper) {
+    const AdamEntry e = table[blockIdx.x];
+    const float step_size = hyper[0], inv_sqrt_bc2 = hyper[1], b1 = hyper[2], b2 = hyper[3], eps = hyper[4], wd = hyper[5];
+    for (long long i = threadIdx.x; i < e.n; i += NT) {
+        const float p = e.p[i];
+        const float g = fmaf(wd, p, e.g[i]);
+        const float m = fmaf(1.0f - b1, g - e.m[i], e.m[i]);
+        const float v = fmaf(1.0f - b2, g * g, b2 * e.v[i]);
+        e.m[i] = m; e.v[i] = v;
+        e.p[i] = p - step_size * (m / (sqrtf(v) * inv_sqrt_bc2 + eps));
+    }
+}
+
 void launch_reduce(const float* partial, int nblocks, int stride, int mcount, int ld, float* out, int nvec, float* v0,
                    float* v1, float* v2, hipStream_t s) {
     ReduceArgs r{partial, nblocks, stride, mcount, ld, out, nvec, {v0, v1, v2}};
@@ -1094,4 +1109,20 @@ extern "C" int mgn_adam_step(const void* table_dev, int32_t n_entries, float lr,
     hipLaunchKernelGGL(adam_kernel, dim3(n_entries), dim3(NT), 0, (hipStream_t)stream, (const AdamEntry*)table_dev,
                        (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay);
     return check_launch("mgn_adam_step");
+}
+
+extern "C" int mgn_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float* hyper6) {
+    MGN_REQUIRE(hyper6 && step >= 1 && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f, "mgn_adam_hyper");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hyper6[0] = (float)((double)lr / bc1); hyper6[1] = (float)(1.0 / sqrt(bc2));
+    hyper6[2] = beta1; hyper6[3] = beta2; hyper6[4] = eps; hyper6[5] = weight_decay;
+    return 0;
+}
+
+extern "C" int mgn_adam_step_dev(const void* table_dev, int32_t n_entries, const float* hyper_dev, void* stream) {
+    MGN_REQUIRE(n_entries >= 0, "mgn_adam_step_dev");
+    if (n_entries == 0) return 0;
+    MGN_REQUIRE(table_dev && hyper_dev, "mgn_adam_step_dev");
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(n_entries), dim3(NT), 0, (hipStream_t)stream, (const AdamEntry*)table_dev, hyper_dev);
+    return check_launch("mgn_adam_step_dev");
 }

@@ -479,12 +479,12 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         return cached
 
     @_on_graph_device
-    def loss(self, graph):
+    def loss(self, graph, check_range: bool = True):
         """Masked squared error between the normalised target delta and the prediction
         (core/meshgraphnet.py:285-304): returns (total, ux, uy, phi).  The output normaliser
         accumulates first (:290).  With gradients enabled the result carries the backward pass
         of the HIP training kernels, so ``loss.backward()`` fills ``.grad`` of every parameter
-        as run_train_multiscale.py:139-141 expects."""
+        as run_train_multiscale.py:139-141 expects.  ``check_range`` as in :meth:`predict`."""
         from . import training
         if self.attention or self.sample_ratio > 0:
             raise NotImplementedError("loss(): the training kernels cover the configuration every shipped config uses "
@@ -495,7 +495,8 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             comps = training.loss_components(self, graph, tgt)
         else:
             comps, _ = training.forward_saving(self, graph, tgt)
-        ops.raise_if_out_of_range("loss")
+        if check_range:
+            ops.raise_if_out_of_range("loss")
         return comps[0] + comps[1] + comps[2], comps[0], comps[1], comps[2]
 
     def save_model(self, path):

@@ -18,10 +18,44 @@ CHUNK = 1 << 14          # elements per workgroup
 
 
 class FusedAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    """``capturable=True``: the scalars of the update (learning rate, bias corrections) travel through a pinned host
+    record and a device record instead of kernel arguments, and the pointer table is uploaded with an asynchronous
+    copy, so that ``step()`` can be captured in a HIP graph (``gnn_amd.training.CapturedTrainStep``); before every
+    replay :meth:`advance_host` does the host part of a step.  Results are the same bit for bit."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, capturable=False):
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError("FusedAdam: invalid hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.capturable = bool(capturable)
+
+    def _write_hyper(self, gi, group, step):
+        """Fills the pinned host record of group ``gi`` for step number ``step``.  The asynchronous copy of the
+        previous step reads the same record when the GPU gets to it, not when it was enqueued: wait for it first."""
+        rec = self.__dict__.setdefault("_hyper", {}).get(gi)
+        if rec is None:
+            host = torch.zeros(8, dtype=torch.float32).pin_memory()
+            rec = self._hyper[gi] = [host, torch.zeros(8, dtype=torch.float32, device=group["params"][0].device), None]
+        if rec[2] is not None:
+            if not torch.cuda.is_current_stream_capturing():     # (a capture starts from a synchronised device)
+                rec[2].synchronize()
+            rec[2] = None
+        rc = _lib.lib().mgn_adam_hyper(float(group["lr"]), float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                                       float(group["weight_decay"]), int(step), C.c_void_p(rec[0].data_ptr()))
+        _lib.check(rc, "mgn_adam_hyper")
+        return rec
+
+    def advance_host(self):
+        """The host part of a step whose device part is replayed from a captured graph: step counts, and the update's
+        scalars (from the current ``lr`` of every group) into the pinned records the graph copies from.  The caller
+        makes sure the previous replay has finished (its copy reads the same records)."""
+        for gi, group in enumerate(self.param_groups):
+            hit = self.__dict__.get("_fast", {}).get(gi)
+            if hit is None:
+                continue
+            for st in hit[1]:
+                st["step"] += 1
+            self._write_hyper(gi, group, hit[1][0]["step"])
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -79,15 +113,38 @@ class FusedAdam(torch.optim.Optimizer):
                         b = 4 * off
                         rows.append((p.data_ptr() + b, g.data_ptr() + b, st["exp_avg"].data_ptr() + b,
                                      st["exp_avg_sq"].data_ptr() + b, min(CHUNK, n - off)))
-                table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev, non_blocking=False)
-                hit = (key if not keep else None, table, len(rows), keep)      # copies of strided gradients are not reusable
+                host_rows = torch.from_numpy(np.asarray(rows, dtype=np.int64))
+                if self.capturable:
+                    # asynchronous upload from a pinned buffer that is kept (allocating pinned memory is not legal under
+                    # stream capture, an asynchronous copy from it is); the previous copy may not have run yet: wait
+                    rec = self._write_hyper(gi, group, step)            # creates the record, waits for its event
+                    pin = self.__dict__.setdefault("_pinned_rows", {}).get(gi)
+                    if pin is None or pin.shape != host_rows.shape:
+                        pin = self._pinned_rows[gi] = torch.empty(host_rows.shape, dtype=torch.int64).pin_memory()
+                    pin.copy_(host_rows)
+                    host_rows = pin
+                    table = torch.empty(host_rows.shape, dtype=torch.int64, device=dev)
+                    table.copy_(host_rows, non_blocking=True)
+                else:
+                    table = host_rows.to(dev, non_blocking=False)
+                # copies of strided gradients are not reusable; the pinned rows live as long as the table (a captured copy reads them)
+                hit = (key if not keep else None, table, len(rows), keep, host_rows)
                 cache[gi] = hit
             with torch.cuda.device(dev):
-                rc = _lib.lib().mgn_adam_step(C.c_void_p(hit[1].data_ptr()), hit[2], float(group["lr"]),
-                                              float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
-                                              float(group["weight_decay"]), int(step),
-                                              C.c_void_p(torch.cuda.current_stream().cuda_stream))
-            _lib.check(rc, "mgn_adam_step")
+                stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+                if self.capturable:
+                    rec = self._write_hyper(gi, group, step)
+                    rec[1].copy_(rec[0], non_blocking=True)
+                    rc = _lib.lib().mgn_adam_step_dev(C.c_void_p(hit[1].data_ptr()), hit[2], C.c_void_p(rec[1].data_ptr()), stream)
+                    _lib.check(rc, "mgn_adam_step_dev")
+                    if not torch.cuda.is_current_stream_capturing():
+                        rec[2] = torch.cuda.Event()
+                        rec[2].record()
+                else:
+                    rc = _lib.lib().mgn_adam_step(C.c_void_p(hit[1].data_ptr()), hit[2], float(group["lr"]),
+                                                  float(group["betas"][0]), float(group["betas"][1]), float(group["eps"]),
+                                                  float(group["weight_decay"]), int(step), stream)
+                    _lib.check(rc, "mgn_adam_step")
         return loss
 
     def load_state_dict(self, state_dict):

@@ -372,6 +372,13 @@ int mgn_train_loss_bwd(const float* decoded, const float* target_norm, const flo
 int mgn_adam_step(const void* table_dev, int32_t n_entries, float lr, float beta1, float beta2, float eps,
                   float weight_decay, int64_t step, void* stream);
 
+/* The same step for captured (HIP graph) launch sequences, whose kernel arguments are fixed at capture time: the
+ * six scalars of the update live in device memory, hyper_dev = {lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), beta1,
+ * beta2, eps, weight_decay}.  mgn_adam_hyper fills that record on the host (the arithmetic of mgn_adam_step); the
+ * caller copies it to the device before every step or replay.  Same results as mgn_adam_step bit for bit. */
+int mgn_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float* hyper6 /*host*/);
+int mgn_adam_step_dev(const void* table_dev, int32_t n_entries, const float* hyper_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

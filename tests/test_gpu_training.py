@@ -403,3 +403,76 @@ def test_loss_grads_irregular_graph():
     unfused = training.backward(model, saved, torch.ones(3, device=DEV))
     worst = max((rel_l2(grads[k], unfused[k].cpu()), k) for k in grads)
     assert worst[0] < 2e-6, worst
+
+
+def test_fused_adam_capturable_equals_plain():
+    """FusedAdam(capturable=True) (scalars through a device record, table through a pinned buffer) gives the bits of
+    the plain optimiser over 5 steps with a changing learning rate."""
+    from gnn_amd.optim import FusedAdam
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(128, 384), (128,), (40000,)]
+    a = [torch.randn(*sh, generator=gen).to(DEV).requires_grad_(True) for sh in shapes]
+    b = [p.detach().clone().requires_grad_(True) for p in a]
+    oa, ob = FusedAdam(a, lr=1e-2, weight_decay=1e-5), FusedAdam(b, lr=1e-2, weight_decay=1e-5, capturable=True)
+    for it in range(5):
+        for p, q in zip(a, b):
+            g = torch.randn(*p.shape, generator=gen).to(DEV)
+            p.grad, q.grad = g.clone(), g.clone()
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = 1e-2 / (it + 1)
+            o.step()
+    for p, q in zip(a, b):
+        assert torch.equal(p.detach(), q.detach())
+    assert oa.state[a[0]]["step"] == ob.state[b[0]]["step"] == 5
+
+
+def test_captured_train_step_equals_eager_sequence():
+    """run_train_multiscale.py:137-142 on a small mesh, seven frames with different noise and a learning-rate change:
+    the captured step (first call eager, second captured, then replays) leaves the same parameters, normaliser
+    statistics and loss values as the eager loop, bit for bit."""
+    import gnn_amd
+    from gnn_amd.optim import FusedAdam
+    from gnn_amd.training import CapturedTrainStep
+    cfg = O.OracleConfig(process_steps=3)
+    sd = O.init_state_dict(cfg, 4)
+    frames = gnn_amd.synthetic_frames(14, 9, n_frames=8, seed=3)
+    gen = torch.Generator().manual_seed(5)
+    batch = []
+    for t in range(7):
+        fr = gnn_amd.MeshGraph(**dict(frames[t].items()))
+        fr["swelling_phi"] = torch.stack([frames[t]["swelling_phi"], frames[t + 1]["swelling_phi"]]).T.contiguous()
+        fr["target"] = torch.cat([frames[t + 1]["world_pos"], frames[t + 1]["phi"]], -1).unsqueeze(0)
+        fr["world_pos"] = fr["world_pos"] + 1e-3 * torch.randn(fr["world_pos"].shape, generator=gen)
+        batch.append(fr)
+
+    def run(captured):
+        model = build_model(cfg, sd).train()
+        opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=captured)
+        stepper = CapturedTrainStep(model, opt) if captured else None
+        losses = []
+        for it, fr in enumerate(batch):
+            if it == 4:
+                opt.param_groups[0]["lr"] = 3e-4
+            if captured:
+                losses.append(torch.stack(stepper(fr)))
+            else:
+                opt.zero_grad()
+                out = model.loss(fr.to(DEV))
+                out[0].backward()
+                opt.step()
+                losses.append(torch.stack([o.detach() for o in out]))
+        if captured:
+            assert stepper.graph is not None            # replays happened
+            stepper.close()
+        return model, opt, torch.stack(losses)
+
+    m_e, o_e, l_e = run(False)
+    m_c, o_c, l_c = run(True)
+    assert torch.equal(l_e, l_c), (l_e, l_c)
+    for (k, p), (_, q) in zip(m_e.named_parameters(), m_c.named_parameters()):
+        assert torch.equal(p, q), k
+    for a, b in ((m_e.node_features_normalizer, m_c.node_features_normalizer), (m_e.edge_features_normalizer, m_c.edge_features_normalizer),
+                 (m_e.output_normalizer, m_c.output_normalizer)):
+        assert a._acc_count == b._acc_count and a._num_accumulations == b._num_accumulations == 7
+        assert torch.equal(a._acc_sum, b._acc_sum) and torch.equal(a._acc_sum_squared, b._acc_sum_squared)
+    assert o_e.state[next(m_e.parameters())]["step"] == o_c.state[next(m_c.parameters())]["step"] == 7
