@@ -220,6 +220,38 @@ def other_configs(device, cpu=True):
         out["bending_rollout"]["cpu_baseline"] = {"value": 1.0 / dtc, "unit": "rollout steps/s", "cores": torch.get_num_threads(),
                                                   "kind": "port", "sample": "20 predict calls of the CPU oracle on the same mesh",
                                                   "ms_per_step": dtc * 1e3}
+    # training step on the same mesh (the size of the reference's own training log): eager, and replayed from a captured graph
+    from gnn_amd.optim import FusedAdam
+    from gnn_amd.training import CapturedTrainStep
+    fr = frames[0]
+    fr = gnn_amd.MeshGraph(**dict(fr.items()))
+    fr["swelling_phi"] = torch.stack([frames[0]["swelling_phi"], frames[1]["swelling_phi"]]).T.contiguous()
+    fr["target"] = torch.cat([frames[1]["world_pos"], frames[1]["phi"]], -1).unsqueeze(0)
+    fr = fr.to(device)
+    tr = {}
+    for captured in (False, True):
+        mt = make_model(10, device).train()
+        opt = FusedAdam(mt.parameters(), lr=1e-4, weight_decay=1e-5, capturable=captured)
+        stepper = CapturedTrainStep(mt, opt) if captured else None
+
+        def one():
+            if captured:
+                return stepper(fr)
+            opt.zero_grad()
+            out = mt.loss(fr)
+            out[0].backward()
+            opt.step()
+            return out
+        for _ in range(5):
+            one()
+        torch.cuda.synchronize(device); t0 = time.perf_counter()
+        for _ in range(50):
+            one()
+        torch.cuda.synchronize(device); dtt = (time.perf_counter() - t0) / 50
+        tr["captured_graph" if captured else "eager"] = {"steps_per_s": 1.0 / dtt, "ms_per_step": dtt * 1e3}
+        if captured:
+            stepper.close()
+    out["bending_training"] = {"workload": "33x17-node bending mesh, 10 MP steps: loss + backward + fused Adam per step", **tr}
     g = gnn_amd.batch_graphs([gnn_amd.synthetic_frames(316, 316, seed=0)[0]] * 8).to(device)
     m = make_model(15, device).eval()
     e = g["edge_index"].shape[1]
