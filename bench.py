@@ -415,6 +415,14 @@ def main():
                                # arrays: copy 4.7-5.4, 2 reads + 1 write 4.7-5.3 TB/s)
                                "moved_GBs": (traffic / t_edge / 1e9) if traffic else None,
                                "streaming_kernel_GBs_measured": [4700.0, 5400.0]}
+            if "mp_node" in kern_ms:
+                # second kernel of the step: node update + next block's projections, 2560 algorithmic bytes per node
+                # (x and aggr in; x, ps, pr out); the last block writes no projections (averaged like the edge kernel)
+                per_node = 2560.0 - 1024.0 / args.mp_steps
+                t_node = kern_ms["mp_node"] * 1e-3
+                out["roofline_node_kernel"] = {"kernel": "mp_node_h_kernel", "bound": "hbm", "achieved": per_node * n_local / t_node / 1e9,
+                                               "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": per_node * n_local / t_node / 1e9 / PEAK_HBM_GBS,
+                                               "traffic": None, "avg_launch_ms": kern_ms["mp_node"], "bytes_per_node_algorithmic": per_node}
             # one MP step = everything the processor launches for one layer; the projection of
             # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
             n_layers = args.steps * args.mp_steps
