@@ -333,8 +333,6 @@ class PackedWeights:
         key = tuple(p.data_ptr() for p in params)
         if key != self.key:
             nb = len(blocks)
-            if 6 * nb > _lib.MAX_PACK_SLICES:
-                raise RuntimeError(f"PackedWeights: at most {_lib.MAX_PACK_SLICES // 6} blocks per table")
             sl, sizes = [], []
             for i in range(nb):
                 e0, e1, n0, n1 = params[4 * i: 4 * i + 4]
@@ -347,12 +345,15 @@ class PackedWeights:
                 for t, col0, k in sets:
                     sl.append(_lib.MgnWeightSlice(t.data_ptr(), t.shape[1], col0, k, 0))
                     sizes.append(int(_lib.lib().mgn_packed_weight_bytes(k)))
-            self.table = (_lib.MgnWeightSlice * len(sl))(*sl)
             self.count = len(sl)
             self.buf = torch.empty(sum(sizes), dtype=torch.uint8, device=params[0].device)
             base, offs = self.buf.data_ptr(), [0]
             for sz in sizes:
                 offs.append(offs[-1] + sz)
+            # one mgn_pack_weights call takes at most MAX_PACK_SLICES sets: (table, count, byte offset of its first set)
+            cap = _lib.MAX_PACK_SLICES
+            self.calls = [((_lib.MgnWeightSlice * len(sl[i: i + cap]))(*sl[i: i + cap]), len(sl[i: i + cap]), offs[i])
+                          for i in range(0, len(sl), cap)]
             self.edge, self.node = [], []
             j = 0
             for i in range(nb):
@@ -363,8 +364,9 @@ class PackedWeights:
                 j += 6 if i + 1 < nb else 4
             self.keep = params                      # the table holds raw addresses of these tensors
             self.key = key
-        rc = _lib.lib().mgn_pack_weights(self.table, self.count, C.c_void_p(self.buf.data_ptr()), _stream())
-        _lib.check(rc, "mgn_pack_weights")
+        for table, count, off in self.calls:
+            rc = _lib.lib().mgn_pack_weights(table, count, C.c_void_p(self.buf.data_ptr() + off), _stream())
+            _lib.check(rc, "mgn_pack_weights")
         return self
 
 

@@ -125,10 +125,10 @@ def test_edge_update_in_receiver_subranges():
     assert torch.equal(a3, a1) and torch.equal(ef, before)
 
 
-@pytest.mark.parametrize("nx,ny,nblocks", [(32, 16, 3), (5, 4, 1), (120, 70, 2)])
+@pytest.mark.parametrize("nx,ny,nblocks", [(32, 16, 3), (5, 4, 1), (120, 70, 2), (9, 6, 21)])
 def test_prepared_weight_sets_change_nothing(nx, ny, nblocks, matmul_mode):
-    """A stack of blocks run through the *_packed entry points (weight sets converted once by mgn_pack_weights) equals
-    the plain entry points bit for bit, in the fp16-split path that uses the sets and in the two that ignore them;
+    """A stack of blocks run through the *_packed entry points (weight sets converted once by mgn_pack_weights; 21 blocks
+    = 124 sets need two calls) equals the plain entry points bit for bit, in the fp16-split path that uses the sets and in the two that ignore them;
     sets are a snapshot: after a weight changes, a refresh is needed and sufficient."""
     from gnn_amd import ops
     from gnn_amd.graph import Topology
