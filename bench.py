@@ -438,8 +438,13 @@ def main():
         if world_size == 1 and args.train_steps > 0:
             del model, g
             torch.cuda.empty_cache()
-            out["train"] = train_object(args, device)
-            out["other_configs"] = other_configs(device, cpu=args.cpu_reps > 0)
+            # secondary objects: a failure in one of them is reported in its place and does not cost the headline line
+            for key, fn in (("train", lambda: train_object(args, device)),
+                            ("other_configs", lambda: other_configs(device, cpu=args.cpu_reps > 0))):
+                try:
+                    out[key] = fn()
+                except Exception as ex:             # noqa: BLE001
+                    out[key] = {"error": f"{type(ex).__name__}: {ex}"[:500]}
         print(json.dumps(out), flush=True)
     if world_size > 1:
         import torch.distributed as dist
