@@ -824,6 +824,67 @@ __global__ __launch_bounds__(NT) void segment_sum_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------ attention option, backward
+// Forward (core/meshgraphnet.py:100-108): alpha_e = leaky_relu(<a[s_e], a[r_e]>), w_e = alpha_e / max(sum of alpha over
+// the in-edges of r_e, 1e-6), aggr[r] = sum of w_e * m_e with m_e the block's pre-residual edge output.
+//
+// Per edge (32 lanes, 16 bytes of each row per lane): gw_e = <g_aggr[r_e], m_e> with m_e = e_out - e_in, and the
+// gradient reaching m_e from the sum, w_e * g_aggr[r_e], added to the upstream gradient of e_out (g_e_in, or nothing).
+__global__ __launch_bounds__(NT) void attn_edge_bwd_kernel(const float* __restrict__ g_aggr, const int* __restrict__ recv,
+                                                           const float* __restrict__ e_out, const float* __restrict__ e_in,
+                                                           const float* __restrict__ w, const float* __restrict__ g_e_in,
+                                                           float* __restrict__ gw, float* __restrict__ g_e_out, long long n_edges) {
+    const int l = threadIdx.x & 31;
+    for (long long e = ((long long)blockIdx.x * NT + threadIdx.x) >> 5; e < n_edges; e += ((long long)gridDim.x * NT) >> 5) {
+        const f32x4 ga = *(const f32x4*)(g_aggr + (size_t)recv[e] * H + 4 * l);
+        const f32x4 m = *(const f32x4*)(e_out + (size_t)e * H + 4 * l) - *(const f32x4*)(e_in + (size_t)e * H + 4 * l);
+        float d = (ga[0] * m[0] + ga[1] * m[1]) + (ga[2] * m[2] + ga[3] * m[3]);
+#pragma unroll
+        for (int k = 16; k >= 1; k >>= 1) d += __shfl_xor(d, k, 32);
+        if (l == 0) gw[e] = d;
+        f32x4 o = ga * w[e];
+        if (g_e_in) o += *(const f32x4*)(g_e_in + (size_t)e * H + 4 * l);
+        *(f32x4*)(g_e_out + (size_t)e * H + 4 * l) = o;
+    }
+}
+
+// Per receiver: gradient of the dot products from the gradient of the weights.  With S = sum of alpha, D = max(S, 1e-6) and
+// deg the receiver's in-degree:  g_alpha_e = gw_e / D - deg * [S >= 1e-6] * (sum of gw * alpha) / D^2, times the slope of the
+// leaky ReLU (1 where alpha > 0, else 0.01).  The factor deg is what autograd computes for the reference's in-place
+// ``alpha[col] = alpha[col].clamp(min=1e-6)`` (core/meshgraphnet.py:106): the assignment through an index with repeats hands
+// the gradient of a receiver's denominator to each of its deg copies, and all of them flow back into the one sum.
+__global__ void attn_alpha_bwd_kernel(const int* __restrict__ rowptr, const float* __restrict__ alpha,
+                                      const float* __restrict__ gw, float* __restrict__ gdot, int n_nodes) {
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += gridDim.x * blockDim.x) {
+        const int b = rowptr[n], e = rowptr[n + 1];
+        float s = 0.f, t = 0.f;
+        for (int k = b; k < e; ++k) { s += alpha[k]; t += gw[k] * alpha[k]; }
+        const float d = fmaxf(s, 1e-6f);
+        const float c = (s >= 1e-6f) ? (float)(e - b) * t / (d * d) : 0.f;
+        for (int k = b; k < e; ++k) gdot[k] = (gw[k] / d - c) * (alpha[k] > 0.f ? 1.0f : 0.01f);
+    }
+}
+
+// Per node v: out[v] (+)= sum over its edge list (rowptr, optionally through `order`) of gdot[e] * a[other[e]]:
+// with the receiver CSR and other = sender this is the gradient of a[receiver], with the sender view and other = receiver
+// that of a[sender].  Fixed summation order.
+__global__ __launch_bounds__(NT) void attn_node_grad_kernel(const float* __restrict__ a, const int* __restrict__ rowptr,
+                                                            const int* __restrict__ order, const int* __restrict__ other,
+                                                            const float* __restrict__ gdot, float* __restrict__ out,
+                                                            int accumulate, long long n_nodes) {
+    const int sq = threadIdx.x & 31;
+    for (long long n = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); n < n_nodes; n += (long long)gridDim.x * 8) {
+        const int k0 = rowptr[n], k1 = rowptr[n + 1];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = k0; k < k1; ++k) {
+            const size_t e = order ? (size_t)order[k] : (size_t)k;
+            s += *(const f32x4*)(a + (size_t)other[e] * H + 4 * sq) * gdot[e];
+        }
+        f32x4* o = (f32x4*)(out + n * H + 4 * sq);
+        *o = accumulate ? *o + s : s;
+    }
+}
+
 // ------------------------------------------------------------------------ features, loss
 __global__ void pad_features_kernel(const float* __restrict__ feat, const float* __restrict__ mean_std,
                                     float* __restrict__ out, long long rows, int F) {
@@ -1066,6 +1127,38 @@ extern "C" int mgn_segment_sum(const float* src, const int32_t* rowptr, const in
     hipLaunchKernelGGL(segment_sum_kernel, dim3(stream_grid(n_segments, 8)), dim3(NT), 0, (hipStream_t)stream, src,
                        rowptr, order, out, (long long)n_segments);
     return check_launch("mgn_segment_sum");
+}
+
+extern "C" int mgn_train_attn_edge_bwd(const float* g_aggr, const int32_t* csr_recv, const float* e_out, const float* e_in,
+                                       const float* edge_weight, const float* g_e_in, float* g_weight, float* g_e_out,
+                                       int64_t n_edges, void* stream) {
+    MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31), "mgn_train_attn_edge_bwd");
+    if (n_edges == 0) return 0;
+    MGN_REQUIRE(g_aggr && csr_recv && e_out && e_in && edge_weight && g_weight && g_e_out, "mgn_train_attn_edge_bwd");
+    hipLaunchKernelGGL(attn_edge_bwd_kernel, dim3(stream_grid(n_edges * 32, NT)), dim3(NT), 0, (hipStream_t)stream, g_aggr,
+                       csr_recv, e_out, e_in, edge_weight, g_e_in, g_weight, g_e_out, (long long)n_edges);
+    return check_launch("mgn_train_attn_edge_bwd");
+}
+
+extern "C" int mgn_train_attn_alpha_bwd(const int32_t* rowptr, const float* alpha, const float* g_weight, float* g_dot,
+                                        int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31), "mgn_train_attn_alpha_bwd");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(rowptr && alpha && g_weight && g_dot, "mgn_train_attn_alpha_bwd");
+    hipLaunchKernelGGL(attn_alpha_bwd_kernel, dim3(stream_grid(n_nodes, NT)), dim3(NT), 0, (hipStream_t)stream, rowptr, alpha,
+                       g_weight, g_dot, (int)n_nodes);
+    return check_launch("mgn_train_attn_alpha_bwd");
+}
+
+extern "C" int mgn_train_attn_node_grad(const float* a_proj, const int32_t* rowptr, const int32_t* order,
+                                        const int32_t* other, const float* g_dot, float* out, int32_t accumulate,
+                                        int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0, "mgn_train_attn_node_grad");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(a_proj && rowptr && other && g_dot && out, "mgn_train_attn_node_grad");
+    hipLaunchKernelGGL(attn_node_grad_kernel, dim3(stream_grid(n_nodes, 8)), dim3(NT), 0, (hipStream_t)stream, a_proj, rowptr,
+                       order, other, g_dot, out, (int)accumulate, (long long)n_nodes);
+    return check_launch("mgn_train_attn_node_grad");
 }
 
 extern "C" int mgn_train_pad_features(const float* feat, int32_t n_feat, const float* mean_std, float* out,

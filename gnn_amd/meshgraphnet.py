@@ -486,10 +486,6 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         of the HIP training kernels, so ``loss.backward()`` fills ``.grad`` of every parameter
         as run_train_multiscale.py:139-141 expects.  ``check_range`` as in :meth:`predict`."""
         from . import training
-        if self.attention or self.sample_ratio > 0:
-            raise NotImplementedError("loss(): the training kernels cover the configuration every shipped config uses "
-                                      "(attention off, sample_ratio 0); the attention and multiscale options run in "
-                                      "forward() / predict() / rollout() only")
         tgt = self._normalized_target(graph)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()[1]):
             comps = training.loss_components(self, graph, tgt)

@@ -656,6 +656,37 @@ def train_edge_bwd(e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, 
 
 
 @_timed_op
+def train_attn_edge_bwd(g_aggr, recv, e_out, e_in, edge_weight, g_e_in, g_weight, g_e_out):
+    """Attention option: gradient of the message weights [E] and of the edge MLP's (pre-residual) output [E,H]."""
+    e, n = e_in.shape[0], g_aggr.shape[0]
+    rc = _lib.lib().mgn_train_attn_edge_bwd(
+        _dev(g_aggr, torch.float32, (n, H), "g_aggr"), _dev(recv, torch.int32, (e,), "recv"), _rows128(e_out, "e_out", e),
+        _rows128(e_in, "e_in", e), _dev(edge_weight, torch.float32, (e,), "edge_weight"), _opt(g_e_in, torch.float32, (e, H), "g_e_in"),
+        _dev(g_weight, torch.float32, (e,), "g_weight"), _rows128(g_e_out, "g_e_out", e), e, _stream())
+    _lib.check(rc, "mgn_train_attn_edge_bwd")
+
+
+@_timed_op
+def train_attn_alpha_bwd(rowptr, alpha, g_weight, g_dot):
+    n, e = rowptr.shape[0] - 1, alpha.shape[0]
+    rc = _lib.lib().mgn_train_attn_alpha_bwd(_dev(rowptr, torch.int32, (n + 1,), "rowptr"), _dev(alpha, torch.float32, (e,), "alpha"),
+                                             _dev(g_weight, torch.float32, (e,), "g_weight"), _dev(g_dot, torch.float32, (e,), "g_dot"),
+                                             n, _stream())
+    _lib.check(rc, "mgn_train_attn_alpha_bwd")
+
+
+@_timed_op
+def train_attn_node_grad(a_proj, rowptr, order, other, g_dot, out, accumulate):
+    """out[v] (+)= sum over v's edges (``rowptr``, through ``order`` if given) of g_dot[j] * a_proj[other[j]]."""
+    n, e = out.shape[0], g_dot.shape[0]
+    rc = _lib.lib().mgn_train_attn_node_grad(
+        _dev(a_proj, torch.float32, (None, H), "a_proj"), _dev(rowptr, torch.int32, (n + 1,), "rowptr"),
+        _opt(order, torch.int32, (e,), "order"), _dev(other, torch.int32, (e,), "other"), _dev(g_dot, torch.float32, (e,), "g_dot"),
+        _rows128(out, "out"), 1 if accumulate else 0, n, _stream())
+    _lib.check(rc, "mgn_train_attn_node_grad")
+
+
+@_timed_op
 def segment_sum(src, rowptr, out, order=None):
     n = out.shape[0]
     _dev(rowptr, torch.int32, (n + 1,), "rowptr")

@@ -72,6 +72,9 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
         raise RuntimeError("the training kernels run on the GPU only")
     if model.node_out_dim != 3:
         raise RuntimeError("loss: node_out_dim must be 3")
+    if model.attention and (not fused or halo is not None):
+        raise NotImplementedError("loss() with the attention option runs on the fused default matrix path (MGN_MATMUL=f16x2, "
+                                  "MGN_TRAIN_FUSED unset) of an unpartitioned model only")
     f32 = model._f32
     topo = halo.topology if halo is not None else model.topology(graph)
     n_loc, e, T = topo.num_nodes, topo.num_edges, model.time_dim
@@ -114,52 +117,93 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
     x, enc_n = encoder(model.node_encoder, nf_pad)
     el, enc_e = encoder(model.edge_encoder, ef_pad)
 
-    layers: List[tuple] = []
-    ps, pr, eprime = _empty(n_loc, dev), _empty(n_loc if fused else n, dev), (None if fused else _empty(e, dev))
-    rowptr = topo.rowptr[: n + 1]                   # halo nodes receive nothing here: their rows stay with the owners
-    blocks = list(model.processors)
-    for i, blk in enumerate(blocks):
-        em, nm = blk.edge_mlp, blk.node_mlp
-        w0 = em[0].weight.detach()
-        if fused and i > 0:
-            ps, pr = _empty(n_loc, dev), _empty(n_loc, dev)      # every block's projections are kept for the backward
-        ops.train_linear_fwd(x, w0, 0, ps[:n])
-        if halo is not None:
-            pending = halo.exchange_rows(ps, async_op=True)      # sender projections of the halo nodes
-        ops.train_linear_fwd(x, w0, H, pr[:n], bias=em[0].bias.detach())
-        if halo is not None and pending is not None:
-            pending.wait()
-        last = i + 1 == len(blocks)
-        if fused:
-            # whole edge update in one kernel; hidden activations are recomputed in the backward
-            aggr = torch.zeros(n, H, dtype=torch.float32, device=dev)     # receivers without in-edges stay 0
-            e_next = None if last else _empty(e, dev)      # the edge latents after the last block are unused
-            with ops.timed("mp_edge"):
-                ops.mp_edge(el, ps, pr, topo.rowptr, topo.sender, topo.recv, em.weights(), e_next, aggr)
-            h1e = ve = None
-            if keep_hidden:
+    def run_blocks(blocks, x, el, topo, n, n_loc, e, halo):
+        """A stack of processor blocks on one topology; returns the final node latents and what the backward needs."""
+        layers: List[tuple] = []
+        ps, pr, eprime = _empty(n_loc, dev), _empty(n_loc if fused else n, dev), (None if fused else _empty(e, dev))
+        rowptr = topo.rowptr[: n + 1]               # halo nodes receive nothing here: their rows stay with the owners
+        for i, blk in enumerate(blocks):
+            em, nm = blk.edge_mlp, blk.node_mlp
+            w0 = em[0].weight.detach()
+            if fused and i > 0:
+                ps, pr = _empty(n_loc, dev), _empty(n_loc, dev)      # every block's projections are kept for the backward
+            ops.train_linear_fwd(x, w0, 0, ps[:n])
+            if halo is not None:
+                pending = halo.exchange_rows(ps, async_op=True)      # sender projections of the halo nodes
+            ops.train_linear_fwd(x, w0, H, pr[:n], bias=em[0].bias.detach())
+            if halo is not None and pending is not None:
+                pending.wait()
+            last = i + 1 == len(blocks)
+            att = None
+            if blk.attention:
+                # message weights from the block's input node latents (core/meshgraphnet.py:100-107)
+                a_proj = _empty(n, dev)
+                alpha, wts = torch.empty(e, dtype=torch.float32, device=dev), torch.empty(e, dtype=torch.float32, device=dev)
+                ops.train_linear_fwd(x, blk.attn_lin.weight.detach(), 0, a_proj, bias=blk.attn_lin.bias.detach())
+                ops.edge_attention(a_proj, topo.rowptr, topo.sender, topo.recv, alpha, wts)
+                att = (a_proj, alpha, wts)
+            if fused:
+                # whole edge update in one kernel; hidden activations are recomputed in the backward
+                aggr = torch.zeros(n, H, dtype=torch.float32, device=dev)     # receivers without in-edges stay 0
+                # the edge latents after the last block are unused, except by the backward of the message weights
+                e_next = None if last and att is None else _empty(e, dev)
+                with ops.timed("mp_edge"):
+                    ops.mp_edge(el, ps, pr, topo.rowptr, topo.sender, topo.recv, em.weights(), e_next, aggr,
+                                edge_weight=None if att is None else att[2])
+                h1e = ve = None
+                if keep_hidden:
+                    h1e, ve = _empty(e, dev), _empty(e, dev)
+                    ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
+                    ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
+            else:
                 h1e, ve = _empty(e, dev), _empty(e, dev)
                 ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
                 ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
-        else:
-            h1e, ve = _empty(e, dev), _empty(e, dev)
-            ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
-            ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
-            e_next = None if last else _empty(e, dev)      # the edge latents after the last block are unused
-            ops.train_ln_fwd(ve, em[4].weight.detach(), em[4].bias.detach(), y=eprime,
-                             res=None if last else el, yres=e_next)
-            aggr = _empty(n, dev)
-            ops.segment_sum(eprime, rowptr, aggr)
-        h1n, vn, x_next = _empty(n, dev), _empty(n, dev), _empty(n, dev)
-        ops.train_linear_fwd(x, nm[0].weight.detach(), 0, h1n, b=aggr, koff_b=H, bias=nm[0].bias.detach(), relu=True)
-        ops.train_linear_fwd(h1n, nm[2].weight.detach(), 0, vn, bias=nm[2].bias.detach(), relu=True)
-        ops.train_ln_fwd(vn, nm[4].weight.detach(), nm[4].bias.detach(), res=x, yres=x_next)
-        layers.append((x, el, h1e, ve, aggr, h1n, vn, ps if fused else None, pr if fused else None))
-        x, el = x_next, e_next
+                e_next = None if last else _empty(e, dev)      # the edge latents after the last block are unused
+                ops.train_ln_fwd(ve, em[4].weight.detach(), em[4].bias.detach(), y=eprime,
+                                 res=None if last else el, yres=e_next)
+                aggr = _empty(n, dev)
+                ops.segment_sum(eprime, rowptr, aggr)
+            h1n, vn, x_next = _empty(n, dev), _empty(n, dev), _empty(n, dev)
+            ops.train_linear_fwd(x, nm[0].weight.detach(), 0, h1n, b=aggr, koff_b=H, bias=nm[0].bias.detach(), relu=True)
+            ops.train_linear_fwd(h1n, nm[2].weight.detach(), 0, vn, bias=nm[2].bias.detach(), relu=True)
+            ops.train_ln_fwd(vn, nm[4].weight.detach(), nm[4].bias.detach(), res=x, yres=x_next)
+            layers.append((x, el, h1e, ve, aggr, h1n, vn, ps if fused else None, pr if fused else None,
+                           None if att is None else att + (e_next,)))
+            x, el = x_next, e_next
+
+        return x, layers
+
+    coarse = None
+    if model.sample_ratio > 0:
+        # coarse branch (core/meshgraphnet.py:179-194): its edge latents from the fine fields of the coarse end points,
+        # its node latents = the encoder output of the sampled nodes
+        if halo is not None:
+            raise NotImplementedError("the coarse multiscale branch is not combined with mesh partitioning")
+        cg = model._coarse_graph(graph["mesh_pos"])
+        nc, ec = cg.num_nodes, cg.topology.num_edges
+        efeat_c = torch.empty(ec, 7, dtype=torch.float32, device=dev)
+        ops.edge_features(world, mesh, phi, cg.sender_orig, cg.recv_orig, efeat_c)
+        ms_c = model.coarse_edge_features_normalizer.stats_for(efeat_c, True)
+        ecf_pad = _empty(ec, dev)
+        ops.train_pad_features(efeat_c, ms_c, ecf_pad)
+        elc, enc_c = encoder(model.coarse_edge_encoder, ecf_pad)
+        xc = _empty(nc, dev)
+        ops.gather_rows(x, cg.first, xc)
+    x, layers = run_blocks(list(model.processors), x, el, topo, n, n_loc, e, halo)
+    map_back = None
+    if model.sample_ratio > 0:
+        xc, layers_c = run_blocks(list(model.coarse_processors), xc, elc, cg.topology, nc, nc, ec, None)
+        map_back = torch.zeros(n, H, dtype=torch.float32, device=dev)
+        ops.scatter_rows(xc, cg.first, map_back)                      # :192-193
+        coarse = dict(cg=cg, enc_c=enc_c, layers=layers_c)
 
     dec = model.node_decoder
     hd, decoded = _empty(n, dev), _empty(n, dev)
-    ops.train_linear_fwd(x, dec[0].weight.detach(), 0, hd, bias=dec[0].bias.detach(), relu=True)
+    if map_back is None:
+        ops.train_linear_fwd(x, dec[0].weight.detach(), 0, hd, bias=dec[0].bias.detach(), relu=True)
+    else:                                           # first Linear over cat[fine, coarse mapped back] (:194, :204)
+        ops.train_linear_fwd(x, dec[0].weight.detach(), 0, hd, b=map_back, koff_b=H, bias=dec[0].bias.detach(), relu=True)
     w2p, b2p = _pad_rows(dec[2].weight, dec[2].bias)
     ops.train_linear_fwd(hd, w2p, 0, decoded, bias=b2p)
     loss3 = torch.empty(3, dtype=torch.float32, device=dev)
@@ -167,7 +211,7 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
     if halo is not None:
         halo.all_reduce_(loss3)                     # every term of the loss is a sum over nodes
     saved = dict(topo=topo, halo=halo, fused=fused, enc_n=enc_n, enc_e=enc_e, layers=layers, x_last=x, hd=hd, decoded=decoded, w2p=w2p,
-                 target_norm=target_norm, node_type=node_type)
+                 target_norm=target_norm, node_type=node_type, coarse=coarse, map_back=map_back)
     return loss3, saved
 
 
@@ -198,64 +242,102 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
     grads["node_decoder.2.bias"] = db2p[:n_out].contiguous()
     gx = gdec                                     # reuse: gradient wrt the node latents entering the decoder
     dw, db = g_like(dec[0].weight), vec()
-    ops.train_linear_bwd(gh, scratch, a=saved["x_last"], w=dec[0].weight.detach(), ga=gx, dw=dw, db=db)
+    coarse, gmap = saved.get("coarse"), None
+    if coarse is None:
+        ops.train_linear_bwd(gh, scratch, a=saved["x_last"], w=dec[0].weight.detach(), ga=gx, dw=dw, db=db)
+    else:                                         # first Linear over cat[fine, coarse mapped back]: two column blocks
+        gmap = _empty(n, dev)
+        wd0 = dec[0].weight.detach()
+        ops.train_linear_bwd(gh, scratch, a=saved["x_last"], w=wd0, koff=0, ga=gx, dw=dw, dw_koff=0, db=db)
+        ops.train_linear_bwd(gh, scratch, a=saved["map_back"], w=wd0, koff=H, ga=gmap, dw=dw, dw_koff=H)
     grads["node_decoder.0.weight"], grads["node_decoder.0.bias"] = dw, db
 
-    # ---- processor blocks in reverse
-    ge = None                                     # gradient wrt the edge latents leaving the block
-    g2n, g1n, gaggr, dpr = (_empty(n, dev) for _ in range(4))
-    dps_loc = _empty(n_loc, dev)
-    dps = dps_loc[:n]
-    g2e, g1e = (None if saved["fused"] else _empty(e, dev)), _empty(e, dev)
-    s_rowptr, s_order = topo.sender_view()
-    rowptr = topo.rowptr[: n + 1]
-    blocks = list(model.processors)
-    for i in range(len(blocks) - 1, -1, -1):
-        blk, pre = blocks[i], f"processors.{i}."
-        em, nm = blk.edge_mlp, blk.node_mlp
-        x, el, h1e, ve, aggr, h1n, vn, ps_b, pr_b = saved["layers"][i]
-        # node MLP: x_next = x + LN(ReLU(V2 ReLU(V1 [x, aggr] + c1) + c2))
-        dg, dbt = vec(), vec()
-        ops.train_ln_bwd(vn, nm[4].weight.detach(), g2n, dg, dbt, scratch, g=gx, relu_mask=True)
-        grads[pre + "node_mlp.4.weight"], grads[pre + "node_mlp.4.bias"] = dg, dbt
-        dw, db = g_like(nm[2].weight), vec()
-        ops.train_linear_bwd(g2n, scratch, a=h1n, w=nm[2].weight.detach(), mask=h1n, ga=g1n, dw=dw, db=db)
-        grads[pre + "node_mlp.2.weight"], grads[pre + "node_mlp.2.bias"] = dw, db
-        dw, db = g_like(nm[0].weight), vec()
-        w_n0 = nm[0].weight.detach()
-        ops.train_linear_bwd(g1n, scratch, a=x, w=w_n0, koff=0, res=gx, ga=gx, dw=dw, dw_koff=0, db=db)
-        ops.train_linear_bwd(g1n, scratch, a=aggr, w=w_n0, koff=H, ga=gaggr, dw=dw, dw_koff=H)
-        grads[pre + "node_mlp.0.weight"], grads[pre + "node_mlp.0.bias"] = dw, db
-        # edge MLP: e' = LN(ReLU(W2 ReLU(ps[s] + pr[r] + W0e e) + b2)); upstream = ge + gaggr[receiver]
-        dg, dbt = vec(), vec()
-        dw, db = g_like(em[2].weight), vec()
-        if saved["fused"]:
-            ops.train_edge_bwd(el, ge, gaggr, ps_b, pr_b, topo.sender, topo.recv, rowptr, em[0].weight.detach(),
-                               em[2].weight.detach(), em[2].bias.detach(), em[4].weight.detach(), g1e, dpr, dw, db, dg, dbt,
-                               scratch)
-        else:
-            ops.train_ln_bwd(ve, em[4].weight.detach(), g2e, dg, dbt, scratch, g=ge, gg=gaggr, idx=topo.recv, relu_mask=True)
-            ops.train_linear_bwd(g2e, scratch, a=h1e, w=em[2].weight.detach(), mask=h1e, ga=g1e, dw=dw, db=db)
-        grads[pre + "edge_mlp.4.weight"], grads[pre + "edge_mlp.4.bias"] = dg, dbt
-        grads[pre + "edge_mlp.2.weight"], grads[pre + "edge_mlp.2.bias"] = dw, db
-        dw0, db0 = g_like(em[0].weight), vec()
-        w_e0 = em[0].weight.detach()
-        if ge is None:
-            ge = _empty(e, dev)
-            ops.train_linear_bwd(g1e, scratch, a=el, w=w_e0, koff=2 * H, ga=ge, dw=dw0, dw_koff=2 * H)
-        else:
-            ops.train_linear_bwd(g1e, scratch, a=el, w=w_e0, koff=2 * H, res=ge, ga=ge, dw=dw0, dw_koff=2 * H)
-        # per-node projections: ps = x W0s^T (sender side), pr = x W0r^T + b0 (receiver side)
-        ops.segment_sum(g1e, s_rowptr, dps_loc, order=s_order)
-        if halo is not None:
-            pending = halo.return_rows(dps_loc, async_op=True)   # halo senders' sums go back to their owners
-        if not saved["fused"]:
-            ops.segment_sum(g1e, rowptr, dpr)
-        if halo is not None and pending is not None:
-            pending.wait()
-        ops.train_linear_bwd(dps, scratch, a=x, w=w_e0, koff=0, res=gx, ga=gx, dw=dw0, dw_koff=0)
-        ops.train_linear_bwd(dpr, scratch, a=x, w=w_e0, koff=H, res=gx, ga=gx, dw=dw0, dw_koff=H, db=db0)
-        grads[pre + "edge_mlp.0.weight"], grads[pre + "edge_mlp.0.bias"] = dw0, db0
+    def blocks_backward(blocks, prefix, layers, topo, halo, gx, n, n_loc, e):
+        """Processor blocks in reverse: ``gx`` (gradient wrt the node latents leaving the stack) becomes the gradient wrt
+        those entering it, in place; returns the gradient wrt the edge latents entering it (None without blocks)."""
+        ge = None                                     # gradient wrt the edge latents leaving the block
+        g2n, g1n, gaggr, dpr = (_empty(n, dev) for _ in range(4))
+        dps_loc = _empty(n_loc, dev)
+        dps = dps_loc[:n]
+        g2e, g1e = (None if saved["fused"] else _empty(e, dev)), _empty(e, dev)
+        s_rowptr, s_order = topo.sender_view()
+        rowptr = topo.rowptr[: n + 1]
+        for i in range(len(blocks) - 1, -1, -1):
+            blk, pre = blocks[i], f"{prefix}.{i}."
+            em, nm = blk.edge_mlp, blk.node_mlp
+            x, el, h1e, ve, aggr, h1n, vn, ps_b, pr_b, att = layers[i]
+            # node MLP: x_next = x + LN(ReLU(V2 ReLU(V1 [x, aggr] + c1) + c2))
+            dg, dbt = vec(), vec()
+            ops.train_ln_bwd(vn, nm[4].weight.detach(), g2n, dg, dbt, scratch, g=gx, relu_mask=True)
+            grads[pre + "node_mlp.4.weight"], grads[pre + "node_mlp.4.bias"] = dg, dbt
+            dw, db = g_like(nm[2].weight), vec()
+            ops.train_linear_bwd(g2n, scratch, a=h1n, w=nm[2].weight.detach(), mask=h1n, ga=g1n, dw=dw, db=db)
+            grads[pre + "node_mlp.2.weight"], grads[pre + "node_mlp.2.bias"] = dw, db
+            dw, db = g_like(nm[0].weight), vec()
+            w_n0 = nm[0].weight.detach()
+            ops.train_linear_bwd(g1n, scratch, a=x, w=w_n0, koff=0, res=gx, ga=gx, dw=dw, dw_koff=0, db=db)
+            ops.train_linear_bwd(g1n, scratch, a=aggr, w=w_n0, koff=H, ga=gaggr, dw=dw, dw_koff=H)
+            grads[pre + "node_mlp.0.weight"], grads[pre + "node_mlp.0.bias"] = dw, db
+            # edge MLP: e' = LN(ReLU(W2 ReLU(ps[s] + pr[r] + W0e e) + b2)); upstream = ge + gaggr[receiver]
+            dg, dbt = vec(), vec()
+            dw, db = g_like(em[2].weight), vec()
+            if att is not None:
+                # aggr = sum of w_e * m_e with m_e = e_next - el: the weights' gradient goes back to attn_lin and the
+                # node latents; m_e receives w_e * gaggr[r_e] on top of what reaches e_next
+                a_proj, alpha, wts, e_next = att
+                gw, gdot = torch.empty(e, dtype=torch.float32, device=dev), torch.empty(e, dtype=torch.float32, device=dev)
+                ge_m, ga = _empty(e, dev), _empty(n, dev)
+                ops.train_attn_edge_bwd(gaggr, topo.recv, e_next, el, wts, ge, gw, ge_m)
+                ops.train_attn_alpha_bwd(rowptr, alpha, gw, gdot)
+                ops.train_attn_node_grad(a_proj, rowptr, None, topo.sender, gdot, ga, False)
+                ops.train_attn_node_grad(a_proj, s_rowptr, s_order, topo.recv, gdot, ga, True)
+                dwa, dba = g_like(blk.attn_lin.weight), vec()
+                ops.train_linear_bwd(ga, scratch, a=x, w=blk.attn_lin.weight.detach(), res=gx, ga=gx, dw=dwa, db=dba)
+                grads[pre + "attn_lin.weight"], grads[pre + "attn_lin.bias"] = dwa, dba
+                ops.train_edge_bwd(el, ge_m, torch.zeros_like(gaggr), ps_b, pr_b, topo.sender, topo.recv, rowptr,
+                                   em[0].weight.detach(), em[2].weight.detach(), em[2].bias.detach(), em[4].weight.detach(),
+                                   g1e, dpr, dw, db, dg, dbt, scratch)
+            elif saved["fused"]:
+                ops.train_edge_bwd(el, ge, gaggr, ps_b, pr_b, topo.sender, topo.recv, rowptr, em[0].weight.detach(),
+                                   em[2].weight.detach(), em[2].bias.detach(), em[4].weight.detach(), g1e, dpr, dw, db, dg, dbt,
+                                   scratch)
+            else:
+                ops.train_ln_bwd(ve, em[4].weight.detach(), g2e, dg, dbt, scratch, g=ge, gg=gaggr, idx=topo.recv, relu_mask=True)
+                ops.train_linear_bwd(g2e, scratch, a=h1e, w=em[2].weight.detach(), mask=h1e, ga=g1e, dw=dw, db=db)
+            grads[pre + "edge_mlp.4.weight"], grads[pre + "edge_mlp.4.bias"] = dg, dbt
+            grads[pre + "edge_mlp.2.weight"], grads[pre + "edge_mlp.2.bias"] = dw, db
+            dw0, db0 = g_like(em[0].weight), vec()
+            w_e0 = em[0].weight.detach()
+            if ge is None:
+                ge = _empty(e, dev)
+                ops.train_linear_bwd(g1e, scratch, a=el, w=w_e0, koff=2 * H, ga=ge, dw=dw0, dw_koff=2 * H)
+            else:
+                ops.train_linear_bwd(g1e, scratch, a=el, w=w_e0, koff=2 * H, res=ge, ga=ge, dw=dw0, dw_koff=2 * H)
+            # per-node projections: ps = x W0s^T (sender side), pr = x W0r^T + b0 (receiver side)
+            ops.segment_sum(g1e, s_rowptr, dps_loc, order=s_order)
+            if halo is not None:
+                pending = halo.return_rows(dps_loc, async_op=True)   # halo senders' sums go back to their owners
+            if not saved["fused"]:
+                ops.segment_sum(g1e, rowptr, dpr)
+            if halo is not None and pending is not None:
+                pending.wait()
+            ops.train_linear_bwd(dps, scratch, a=x, w=w_e0, koff=0, res=gx, ga=gx, dw=dw0, dw_koff=0)
+            ops.train_linear_bwd(dpr, scratch, a=x, w=w_e0, koff=H, res=gx, ga=gx, dw=dw0, dw_koff=H, db=db0)
+            grads[pre + "edge_mlp.0.weight"], grads[pre + "edge_mlp.0.bias"] = dw0, db0
+
+        return ge, g2e, g1e, g2n, g1n
+
+    gec = None
+    if coarse is not None:
+        cg = coarse["cg"]
+        nc, ec = cg.num_nodes, cg.topology.num_edges
+        gxc = _empty(nc, dev)
+        ops.gather_rows(gmap, cg.first, gxc)          # rows of the mapped-back tensor that came from the coarse nodes
+        gec, g2ec, g1ec, _, _ = blocks_backward(list(model.coarse_processors), "coarse_processors", coarse["layers"], cg.topology,
+                                                None, gxc, nc, nc, ec)
+    ge, g2e, g1e, g2n, g1n = blocks_backward(list(model.processors), "processors", saved["layers"], topo, halo, gx, n, n_loc, e)
+    if coarse is not None:
+        gx.index_add_(0, cg.first, gxc)               # the coarse nodes' latents are rows of the node encoder's output (:182)
 
     # ---- encoders: y = LN(W1 ReLU(W0 feat + b0) + b1), no gradient wanted for the features
     def encoder_bwd(seq, name, saved_enc, gy, g_a, g_b):
@@ -277,6 +359,12 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
     if g2e is None:
         g2e = _empty(e, dev)
     encoder_bwd(model.edge_encoder, "edge_encoder", saved["enc_e"], ge, g2e, g1e)
+    if coarse is not None:
+        if gec is None:
+            gec = torch.zeros(ec, H, dtype=torch.float32, device=dev)
+        if g2ec is None:
+            g2ec = _empty(ec, dev)
+        encoder_bwd(model.coarse_edge_encoder, "coarse_edge_encoder", coarse["enc_c"], gec, g2ec, g1ec)
     if halo is not None:
         # each rank holds the sums over its own rows: one all-reduce over all 136 tensors (4.84 MB)
         flat = torch.cat([g.reshape(-1) for g in grads.values()])

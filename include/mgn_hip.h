@@ -365,6 +365,26 @@ int mgn_train_loss_fwd(const float* decoded, const float* target_norm, const flo
 int mgn_train_loss_bwd(const float* decoded, const float* target_norm, const float* node_type, const float* grad3,
                        int32_t time_dim, int64_t n_nodes, float* gdecoded, void* stream);
 
+/* Backward of the attention option (core/meshgraphnet.py:100-108; forward: mgn_edge_attention + mgn_mp_edge_weighted).
+ * mgn_train_attn_edge_bwd: per edge, g_weight[j] = <g_aggr[recv[j]], e_out[j] - e_in[j]> (the block's pre-residual
+ * edge output is e_out - e_in) and g_e_out[j] = g_e_in[j] (or 0 when NULL) + edge_weight[j] * g_aggr[recv[j]]: the
+ * gradient that reaches the edge MLP's output; pass g_e_out to mgn_train_edge_bwd with a zero g_aggr.
+ * mgn_train_attn_alpha_bwd: per receiver, g_dot = gradient wrt <a[s], a[r]> from g_weight: g_weight / D minus
+ * in-degree * (sum of g_weight * alpha) / D^2 (nothing through a sum clamped at 1e-6), times the leaky slope 1 / 0.01 by
+ * the sign of alpha.  The in-degree factor is what autograd yields for the reference's in-place clamp through the
+ * repeated index `col` (:106); training with the reference applies it, so this does too.
+ * mgn_train_attn_node_grad: out[v] (+)= sum over v's edge list of g_dot[j] * a_proj[other[j]]; called once with the
+ * receiver CSR (order NULL, other = csr_sender) and once with the sender view (order = edges by sender,
+ * other = csr_recv, accumulate 1): the gradient of attn_lin's output, which then goes through a Linear backward. */
+int mgn_train_attn_edge_bwd(const float* g_aggr /*[N][H]*/, const int32_t* csr_recv, const float* e_out, const float* e_in,
+                            const float* edge_weight /*[E]*/, const float* g_e_in /*[E][H] or NULL*/,
+                            float* g_weight /*[E]*/, float* g_e_out /*[E][H]*/, int64_t n_edges, void* stream);
+int mgn_train_attn_alpha_bwd(const int32_t* rowptr, const float* alpha /*[E]*/, const float* g_weight /*[E]*/,
+                             float* g_dot /*[E]*/, int64_t n_nodes, void* stream);
+int mgn_train_attn_node_grad(const float* a_proj /*[N][H]*/, const int32_t* rowptr, const int32_t* order /*or NULL*/,
+                             const int32_t* other /*[E]*/, const float* g_dot /*[E]*/, float* out /*[N][H]*/,
+                             int32_t accumulate, int64_t n_nodes, void* stream);
+
 /* One Adam step over many tensors in one launch: optimizer.step() of run_train_multiscale.py:115-119,
  * :142 (torch.optim.Adam, amsgrad off: L2 weight decay added to the gradient, bias-corrected moments).
  * table_dev: device array of n_entries records {float* param; const float* grad; float* exp_avg;

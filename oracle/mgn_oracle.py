@@ -322,8 +322,10 @@ def coarse_graph(cfg: OracleConfig, g, start: int):
     mesh_pos, world_pos, phi = g["mesh_pos"], g["world_pos"], g["phi"]
     k = 4 if mesh_pos.shape[-1] == 3 else 3
     n_coarse = max(1, int(mesh_pos.shape[0] * cfg.sample_ratio))
-    first = farthest_point_sampling(mesh_pos, n_coarse, start)
-    cei = knn_graph(mesh_pos[first], k)
+    # the sample and its graph are integer results of float32 arithmetic in the reference: kept in float32 when the
+    # rest of the oracle runs in float64 (gradient checks), so that both precisions see one topology
+    first = farthest_point_sampling(mesh_pos.float(), n_coarse, start)
+    cei = knn_graph(mesh_pos.float()[first], k)
     s, r = first[cei[0]], first[cei[1]]
     rel = mesh_pos[s] - mesh_pos[r]
     relw = world_pos[s] - world_pos[r]
@@ -417,12 +419,12 @@ def predict(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g, coarse_start:
         return cur.unsqueeze(0) + delta
 
 
-def loss(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g):
+def loss(sd, cfg: OracleConfig, norms: Dict[str, NormStats], g, coarse_start: int = 0):
     """Masked squared error on normalised deltas (core/meshgraphnet.py:285-304).
     The output normaliser accumulates before the forward pass runs."""
     cur = torch.cat([g["world_pos"], g["phi"]], dim=-1)
     tgt = norms["output"].normalize(g["target"] - cur)
-    err = (forward(sd, cfg, norms, g) - tgt) ** 2
+    err = (forward(sd, cfg, norms, g, coarse_start=coarse_start) - tgt) ** 2
     parts = []
     for k in range(3):
         keep = ~(g["node_type"][:, k + 1] == 1)

@@ -241,10 +241,15 @@ def test_unsupported_options_raise():
     with pytest.raises(NotImplementedError):
         EncodeProcessDecodeMultiScale(10, 7, hidden_size=64, sample_ratio=0.0, node_out_dim=3)
     g = O.synthetic_graph(4, 3, with_target=True)
-    for kw in (dict(sample_ratio=0.5, coarse_process_steps=1), dict(sample_ratio=0.0, attention=True)):
-        mm = EncodeProcessDecodeMultiScale(10, 7, node_out_dim=3, with_mat_params=False, process_steps=1, device=DEV, **kw).to(DEV)
-        with pytest.raises(NotImplementedError):        # the two options run in forward / predict only
+    mm = EncodeProcessDecodeMultiScale(10, 7, node_out_dim=3, with_mat_params=False, process_steps=1, device=DEV,
+                                       sample_ratio=0.0, attention=True).to(DEV)
+    from gnn_amd import ops
+    prev = ops.set_matmul_mode("f32")
+    try:
+        with pytest.raises(NotImplementedError):        # attention trains on the fused default matrix path only
             mm.loss(graph_to(g, DEV))
+    finally:
+        ops.set_matmul_mode(prev)
     m = EncodeProcessDecodeMultiScale(10, 7, sample_ratio=0.0, node_out_dim=3, with_mat_params=False, process_steps=1)
     with pytest.raises(RuntimeError):       # CPU tensors: no fallback
         m.predict(O.synthetic_graph(2, 2))

@@ -126,7 +126,7 @@ def gpu_loss_and_grads(model, g):
         return out
 
     masks = [saved["enc_n"][1].cpu() > 0, orig(saved["enc_e"][1].cpu() > 0)]
-    for (_x, _e, h1e, ve, _a, h1n, vn, _ps, _pr) in saved["layers"]:
+    for (_x, _e, h1e, ve, _a, h1n, vn, _ps, _pr, _att) in saved["layers"]:
         masks += [orig(h1e.cpu() > 0), orig(ve.cpu() > 0), h1n.cpu() > 0, vn.cpu() > 0]
     masks.append(saved["hd"].cpu() > 0)
     return loss3.cpu(), {k: v.cpu() for k, v in grads.items()}, masks
