@@ -15,14 +15,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(backend):
+def _run(backend, nproc=2):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     env = dict(os.environ, MGN_DIST_BACKEND=backend, OMP_NUM_THREADS="2")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(HERE, "dist_worker.py")]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=110)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
@@ -31,11 +31,18 @@ def _run(backend):
     return json.loads(line[-1][len("DIST_RESULT "):])
 
 
-def _check(r):
-    assert r["finite"] and r["world"] == 2
+def _check(r, world=2):
+    assert r["finite"] and r["world"] == world
     assert r["rollout_rel"] < 1e-6, r
     assert r["loss_rel"] < 1e-5 and r["grad_rel_worst"] < 1e-5, r
 
 
 def test_two_processes_gloo_transport_one_gpu():
     _check(_run("gloo"))
+
+
+def test_one_process_rccl_backend():
+    """The RCCL process group on the one GPU every box has: a single rank whose partition is the whole mesh (empty
+    halos).  Runs the library initialisation, the all-reduces of statistics, loss and gradients and the (empty)
+    all-to-all calls of the partitioned path on device buffers; the exchange between two GPUs is tests/test_zy_rccl.py."""
+    _check(_run("nccl", nproc=1), world=1)
