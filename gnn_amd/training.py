@@ -419,8 +419,13 @@ class CapturedTrainStep:
             raise ValueError("CapturedTrainStep needs FusedAdam(..., capturable=True)")
         if model.__dict__.get("halo") is not None:
             raise NotImplementedError("CapturedTrainStep: not with a partitioned model")
+        if model.sample_ratio > 0 and getattr(model, "coarse_start", None) is None:
+            raise ValueError("CapturedTrainStep: a multiscale model draws its coarse graph per call (model.coarse_start is "
+                             "None); set model.coarse_start to a node id so that the captured step keeps one coarse graph")
         self.model, self.opt = model, optimizer
         self.norms = (model.node_features_normalizer, model.edge_features_normalizer, model.output_normalizer)
+        if model.sample_ratio > 0:
+            self.norms += (model.coarse_edge_features_normalizer,)
         self.graph = self.static = self.out = None
         self.done = None
 

@@ -426,14 +426,17 @@ def test_fused_adam_capturable_equals_plain():
     assert oa.state[a[0]]["step"] == ob.state[b[0]]["step"] == 5
 
 
-def test_captured_train_step_equals_eager_sequence():
+@pytest.mark.parametrize("options", [False, True], ids=["default", "attention+multiscale"])
+def test_captured_train_step_equals_eager_sequence(options):
     """run_train_multiscale.py:137-142 on a small mesh, seven frames with different noise and a learning-rate change:
     the captured step (first call eager, second captured, then replays) leaves the same parameters, normaliser
-    statistics and loss values as the eager loop, bit for bit."""
+    statistics and loss values as the eager loop, bit for bit.  Also with both options of the model on (the coarse
+    graph pinned to one first sample)."""
     import gnn_amd
     from gnn_amd.optim import FusedAdam
     from gnn_amd.training import CapturedTrainStep
-    cfg = O.OracleConfig(process_steps=3)
+    cfg = O.OracleConfig(process_steps=3, attention=True, sample_ratio=0.4, coarse_process_steps=2) if options \
+        else O.OracleConfig(process_steps=3)
     sd = O.init_state_dict(cfg, 4)
     frames = gnn_amd.synthetic_frames(14, 9, n_frames=8, seed=3)
     gen = torch.Generator().manual_seed(5)
@@ -446,7 +449,12 @@ def test_captured_train_step_equals_eager_sequence():
         batch.append(fr)
 
     def run(captured):
-        model = build_model(cfg, sd).train()
+        if options:
+            from test_gpu_options import build
+            model = build(cfg, sd).train()
+            model.coarse_start = 5
+        else:
+            model = build_model(cfg, sd).train()
         opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=captured)
         stepper = CapturedTrainStep(model, opt) if captured else None
         losses = []
@@ -471,8 +479,11 @@ def test_captured_train_step_equals_eager_sequence():
     assert torch.equal(l_e, l_c), (l_e, l_c)
     for (k, p), (_, q) in zip(m_e.named_parameters(), m_c.named_parameters()):
         assert torch.equal(p, q), k
-    for a, b in ((m_e.node_features_normalizer, m_c.node_features_normalizer), (m_e.edge_features_normalizer, m_c.edge_features_normalizer),
-                 (m_e.output_normalizer, m_c.output_normalizer)):
+    pairs = [(m_e.node_features_normalizer, m_c.node_features_normalizer), (m_e.edge_features_normalizer, m_c.edge_features_normalizer),
+             (m_e.output_normalizer, m_c.output_normalizer)]
+    if options:
+        pairs.append((m_e.coarse_edge_features_normalizer, m_c.coarse_edge_features_normalizer))
+    for a, b in pairs:
         assert a._acc_count == b._acc_count and a._num_accumulations == b._num_accumulations == 7
         assert torch.equal(a._acc_sum, b._acc_sum) and torch.equal(a._acc_sum_squared, b._acc_sum_squared)
     assert o_e.state[next(m_e.parameters())]["step"] == o_c.state[next(m_c.parameters())]["step"] == 7
