@@ -390,6 +390,51 @@ def g7_attention_multiscale():
     print("g7_attention_multiscale: ok")
 
 
+def g8_options_loss_grads():
+    """``loss`` + ``backward`` of the reference itself (core/meshgraphnet.py:285-304 through torch autograd) with the
+    attention option, the coarse branch, and both: loss values, and per parameter the norm and the sum of its gradient
+    (the small tensors -- biases, LayerNorm vectors -- in full).  Pins the backward of the two options, including what
+    autograd makes of the in-place clamp through the repeated receiver index (:106).  The oracle's autograd must
+    agree to 2e-6 (the reference's backward is not run-to-run reproducible on CPU)."""
+    g = O.synthetic_graph(14, 9, seed=6, with_target=True)
+    n = g["mesh_pos"].shape[0]
+    out = {"nx": 14, "ny": 9, "graph_seed": 6, "weight_seed": 23}
+    for tag, att, ratio, csteps in (("att", True, 0.0, 0), ("ms", False, 0.5, 2), ("both", True, 0.4, 1)):
+        cfg = O.OracleConfig(process_steps=2, attention=att, sample_ratio=ratio, coarse_process_steps=csteps)
+        m = EncodeProcessDecodeMultiScale(cfg.node_in_dim, cfg.edge_in_dim, hidden_size=128, process_steps=2,
+                                          coarse_process_steps=csteps, node_out_dim=3, attention=att,
+                                          with_mat_params=False, sample_ratio=ratio, time_dim=1, device="cpu")
+        sd = O.init_state_dict(cfg, 23)
+        m.load_state_dict(sd)
+        norms = O.make_norms(cfg)
+        torch.manual_seed(8)
+        start = int(torch.randint(0, n, (1,)))
+        torch.manual_seed(8)
+        m.zero_grad()
+        rl = m.loss(g)
+        rl[0].backward()
+        sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        ol = O.loss(sdg, cfg, norms, g, coarse_start=start)
+        ol[0].backward()
+        for a, b in zip(rl, ol):
+            assert bit_equal(a.detach(), b.detach()), tag
+        names, l2, asum = [], [], []
+        for k, p in m.named_parameters():
+            assert (p.grad is None) == (sdg[k].grad is None), (tag, k)
+            if p.grad is None:
+                continue
+            rel = float((p.grad - sdg[k].grad).double().norm() / p.grad.double().norm().clamp_min(1e-30))
+            assert rel < 2e-6, (tag, k, rel)
+            names.append(k); l2.append(float(p.grad.double().norm())); asum.append(float(p.grad.double().sum()))
+            if p.grad.numel() <= 128:
+                out[f"{tag}_grad__{k}"] = p.grad.numpy().copy()
+        out.update({f"{tag}_loss": np.array([float(v.detach()) for v in rl], dtype=np.float64), f"{tag}_start": start,
+                    f"{tag}_grad_names": np.array(names), f"{tag}_grad_l2": np.array(l2), f"{tag}_grad_sum": np.array(asum),
+                    f"{tag}_sd_digest": O.state_dict_digest(sd)})
+    np.savez_compressed(os.path.join(HERE, "g8_options_loss_grads.npz"), **out)
+    print("g8_options_loss_grads: ok", {t: out[f"{t}_loss"][0] for t in ("att", "ms", "both")})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:                       # regenerate only the named fixtures, e.g. `make_golden.py g6_dataset`
@@ -404,4 +449,5 @@ if __name__ == "__main__":
     g5_rollout()
     g6_dataset()
     g7_attention_multiscale()
+    g8_options_loss_grads()
     print("all fixtures written to", HERE)

@@ -292,3 +292,29 @@ def test_attention_training_loop_reduces_the_loss():
         opt.step()
         losses.append(float(out[0].detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("tag,att,ratio,csteps", [("att", True, 0.0, 0), ("ms", False, 0.5, 2), ("both", True, 0.4, 1)])
+def test_options_loss_grads_golden(tag, att, ratio, csteps):
+    """Fixture G8 (the reference's own ``loss`` + ``backward`` with the two options, fresh statistics): loss values to
+    1e-4 (fresh statistics: the variance is E[x^2] - E[x]^2 in fp32), every parameter gradient's norm and the small
+    gradient tensors to 5e-3 (ReLU flips, as in the comparisons with the oracle above)."""
+    d = np.load(f"{GOLDEN}/g8_options_loss_grads.npz")
+    cfg = O.OracleConfig(process_steps=2, attention=att, sample_ratio=ratio, coarse_process_steps=csteps)
+    sd = O.init_state_dict(cfg, int(d["weight_seed"]))
+    model = build(cfg, sd).train()
+    model.coarse_start = int(d[f"{tag}_start"])
+    g = graph_to(O.synthetic_graph(int(d["nx"]), int(d["ny"]), seed=int(d["graph_seed"]), with_target=True), DEV)
+    out = model.loss(g)
+    out[0].backward()
+    for c in range(4):
+        ref = float(d[f"{tag}_loss"][c])
+        assert abs(float(out[c].detach()) - ref) <= 1e-4 * abs(ref), (c, float(out[c].detach()), ref)
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    for name, l2 in zip(d[f"{tag}_grad_names"], d[f"{tag}_grad_l2"]):
+        got = float(grads[str(name)].double().norm())
+        assert abs(got - l2) <= 5e-3 * l2, (str(name), got, l2)
+    pre = f"{tag}_grad__"
+    for k in d.files:
+        if k.startswith(pre):
+            assert rel_l2(grads[k[len(pre):]], torch.from_numpy(d[k])) < 5e-3, k

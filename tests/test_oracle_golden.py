@@ -156,3 +156,48 @@ def test_oracle_attention_and_multiscale_golden(tag, att, ratio, csteps):
         ce, cei, first = O.coarse_graph(cfg, g, int(d[f"{tag}_start1"]))
         assert np.array_equal(first.numpy(), d[f"{tag}_first1"]) and np.array_equal(cei.numpy(), d[f"{tag}_coarse_edge_index1"])
         assert norms["coarse_edge"].acc_count == int(d[f"{tag}_out_coarse_edge_count"])
+
+
+@pytest.mark.parametrize("tag,att,ratio,csteps", [("att", True, 0.0, 0), ("ms", False, 0.5, 2), ("both", True, 0.4, 1)])
+def test_oracle_options_loss_grads_golden(tag, att, ratio, csteps):
+    """Fixture G8: ``loss`` + ``backward`` of the reference model itself with attention, the coarse branch and both
+    (fresh statistics, first sample of the coarse graph as drawn by the reference): the oracle's loss values, the
+    norm of every parameter gradient and the small gradient tensors in full.  This is what pins the backward of the
+    attention weights, including the in-degree factor autograd produces for ``alpha[col] = alpha[col].clamp(...)``
+    (core/meshgraphnet.py:106)."""
+    d = np.load(f"{GOLDEN}/g8_options_loss_grads.npz")
+    cfg = O.OracleConfig(process_steps=2, attention=att, sample_ratio=ratio, coarse_process_steps=csteps)
+    sd = O.init_state_dict(cfg, int(d["weight_seed"]))
+    assert O.state_dict_digest(sd) == float(d[f"{tag}_sd_digest"])
+    g = O.synthetic_graph(int(d["nx"]), int(d["ny"]), seed=int(d["graph_seed"]), with_target=True)
+    sdg = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    ls = O.loss(sdg, cfg, O.make_norms(cfg), g, coarse_start=int(d[f"{tag}_start"]))
+    ls[0].backward()
+    assert np.allclose([float(v.detach()) for v in ls], d[f"{tag}_loss"], rtol=1e-6)
+    names = [str(k) for k in d[f"{tag}_grad_names"]]
+    assert any("attn_lin" in k for k in names) == att and any(k.startswith("coarse_") for k in names) == (ratio > 0)
+    for name, l2 in zip(names, d[f"{tag}_grad_l2"]):
+        got = float(sdg[name].grad.double().norm())
+        assert abs(got - l2) <= 1e-4 * max(l2, 1e-12), name
+    pre = f"{tag}_grad__"
+    for k in d.files:
+        if k.startswith(pre):
+            assert rel_l2(sdg[k[len(pre):]].grad, torch.from_numpy(d[k])) < 1e-4, k
+
+
+def test_attention_gradient_carries_the_in_degree_factor():
+    """The reference's expression for the message weights (core/meshgraphnet.py:101-107) differentiated by torch, against
+    the closed form the HIP backward uses: g_alpha = gw / D - deg * [S >= 1e-6] * sum(gw * alpha) / D^2."""
+    gen = torch.Generator().manual_seed(0)
+    rcv = torch.tensor([0, 0, 0, 1, 1, 2, 4, 4, 4, 4])
+    al = torch.rand(10, dtype=torch.float64, generator=gen).requires_grad_(True)
+    den = torch.zeros(5, dtype=torch.float64).scatter_add_(0, rcv, al)
+    den[rcv] = den[rcv].clamp(min=1e-6)
+    gw = torch.rand(10, dtype=torch.float64, generator=gen)
+    ((al / den[rcv]) * gw).sum().backward()
+    a = al.detach()
+    S = torch.zeros(5, dtype=torch.float64).scatter_add_(0, rcv, a)
+    t = torch.zeros(5, dtype=torch.float64).scatter_add_(0, rcv, gw * a)
+    deg = torch.bincount(rcv, minlength=5).double()
+    closed = gw / S[rcv] - deg[rcv] * t[rcv] / S[rcv] ** 2
+    assert torch.allclose(al.grad, closed, rtol=1e-12, atol=1e-14)
