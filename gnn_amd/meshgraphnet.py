@@ -154,16 +154,17 @@ class EdgeNodeMessagePassing(nn.Module):
         wts = None
         if self.attention:
             # message weights from the OLD node latents (core/meshgraphnet.py:101-107): a = attn_lin(x), then per edge
-            # leaky_relu(<a[s], a[r]>) over its sum per receiver
-            if halo is not None:
-                raise NotImplementedError("attention is not combined with mesh partitioning")
+            # leaky_relu(<a[s], a[r]>) over its sum per receiver.  On a partitioned mesh the projected rows of the halo
+            # nodes come from their owners (every receiver is owned, so its sum is complete on this rank).
             buf = self.__dict__.get("_att")
             if buf is None or buf[0].shape[0] != x.shape[0] or buf[1].shape[0] != e_csr.shape[0] or buf[0].device != x.device:
                 buf = (torch.empty_like(x), torch.empty(e_csr.shape[0], dtype=torch.float32, device=x.device),
                        torch.empty(e_csr.shape[0], dtype=torch.float32, device=x.device))
                 self.__dict__["_att"] = buf
             a_proj, alpha, wts = buf
-            ops.train_linear_fwd(x, self.attn_lin.weight.data, 0, a_proj, bias=self.attn_lin.bias.data)
+            ops.train_linear_fwd(x[:n], self.attn_lin.weight.data, 0, a_proj[:n], bias=self.attn_lin.bias.data)
+            if halo is not None:
+                halo.exchange_rows(a_proj)
             ops.edge_attention(a_proj, topo.rowptr, topo.sender, topo.recv, alpha, wts)
         if halo is None and not ops.timing_enabled():       # the common path, without the timing contexts
             if not projected:
@@ -193,12 +194,14 @@ class EdgeNodeMessagePassing(nn.Module):
             with ops.timed("halo_exchange"):
                 pending = halo.exchange_rows(ps, async_op=True)
             with ops.timed("mp_edge"):
-                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=halo.interior)
+                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=halo.interior,
+                            edge_weight=wts)
             if pending is not None:
                 pending.wait()
             with ops.timed("mp_edge_boundary"):
                 for rng in halo.boundary:
-                    ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=rng)
+                    ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=rng,
+                                edge_weight=wts)
         with ops.timed("mp_node"):
             if next_block is None:
                 ops.mp_node(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, x[:n])

@@ -237,8 +237,6 @@ def mp_edge(e_in, ps, pr, rowptr, csr_sender, csr_recv, mlp: MlpWeights, e_out, 
         n_sub = n1 - n0
         if n_sub == 0 or e_sub == 0:
             return
-    if edge_weight is not None and node_range is not None:
-        raise RuntimeError("mp_edge: weighted messages are not combined with receiver sub-ranges")
     if packed is not None:
         rc = _lib.lib().mgn_mp_edge_packed(
             _dev(e_in, torch.float32, (ne, H), "e_in"), _dev(ps, torch.float32, (n, H), "ps"),

@@ -103,12 +103,19 @@ def _thread_plan(ei, n, world, rank, bus):
     return ThreadPlan(ei, n, world, rank).to(DEV)
 
 
-@pytest.mark.parametrize("world,nx,ny", [(2, 60, 45), (3, 60, 45), (4, 300, 260)])
-def test_partitioned_rollout_matches_single_gpu(world, nx, ny):
+@pytest.mark.parametrize("world,nx,ny,attention", [(2, 60, 45, False), (3, 60, 45, False), (4, 300, 260, False), (3, 60, 45, True)])
+def test_partitioned_rollout_matches_single_gpu(world, nx, ny, attention):
+    """Also with the attention option: the projected rows of the halo nodes travel like the sender projections."""
     from gnn_amd import partition
     from gnn_amd.graph import MeshGraph
-    from test_gpu_model import build_model
-    cfg = O.OracleConfig(process_steps=4)
+    if attention:
+        from test_gpu_options import build
+
+        def build_model(cfg, sd):
+            return build(cfg, sd)
+    else:
+        from test_gpu_model import build_model
+    cfg = O.OracleConfig(process_steps=4, attention=attention)
     sd = O.init_state_dict(cfg, 3)
     g = O.synthetic_graph(nx, ny, seed=5)          # the largest case: 78k nodes, every launch spans many workgroups
     n = g["mesh_pos"].shape[0]
