@@ -61,11 +61,14 @@ CASES = [("latents x1e-3", 1e-3, 1.0, 1.0, 1), ("latents x1e2", 1e2, 1.0, 1.0, 1
 @pytest.mark.parametrize("name,scale,gamma,wscale,n_layers", CASES, ids=[c[0] for c in CASES])
 def test_default_matrix_path_holds_the_fp32_bar_across_its_envelope(name, scale, gamma, wscale, n_layers):
     from gnn_amd import ops
-    assert ops.matmul_mode() == "f16x2"
-    ops.range_check(reset=True)
-    cfg, sd, g, x, e = _problem(scale, gamma, wscale, n_layers)
-    x64, e64, x32, e32 = _fp64(sd, g, x, e, n_layers)
-    xo, eo = _gpu(sd, g, x, e, n_layers)
+    prev = ops.set_matmul_mode("f16x2")              # the default path, whatever MGN_MATMUL selected for the process
+    try:
+        ops.range_check(reset=True)
+        cfg, sd, g, x, e = _problem(scale, gamma, wscale, n_layers)
+        x64, e64, x32, e32 = _fp64(sd, g, x, e, n_layers)
+        xo, eo = _gpu(sd, g, x, e, n_layers)
+    finally:
+        ops.set_matmul_mode(prev)
     rx, re, fx, fe = rel_l2(xo, x64), rel_l2(eo, e64), rel_l2(x32, x64), rel_l2(e32, e64)
     print(f"{name}: GPU {rx:.2e}/{re:.2e}, fp32 CPU oracle {fx:.2e}/{fe:.2e} (rel-L2 of node / edge latents vs fp64)")
     assert not ops.range_check(reset=True), "range flag raised inside the documented envelope"
