@@ -34,7 +34,19 @@ def edge():
     ops.mp_edge(ef, ps, pr, topo.rowptr, topo.sender, topo.recv, layer.edge_mlp.weights(), ef, aggr, packed=pk.edge[0])
 
 
-for name, fn in (("node", node), ("edge", edge), ("node", node)):
+ef2 = torch.empty_like(ef)
+
+
+def edge_out_of_place():
+    ops.mp_edge(ef, ps, pr, topo.rowptr, topo.sender, topo.recv, layer.edge_mlp.weights(), ef2, aggr, packed=pk.edge[0])
+
+
+def edge_no_store():
+    ops.mp_edge(ef, ps, pr, topo.rowptr, topo.sender, topo.recv, layer.edge_mlp.weights(), None, aggr, packed=pk.edge[0])
+
+
+for name, fn in (("node", node), ("edge", edge), ("node", node), ("edge, e_out to a second buffer", edge_out_of_place),
+                 ("edge", edge), ("edge, e_out not stored", edge_no_store)):
     for _ in range(3):
         fn()
     s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

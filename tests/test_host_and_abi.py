@@ -173,3 +173,13 @@ def test_size_limits_are_rejected_on_the_host():
     # empty inputs are not an error and launch nothing
     assert lib.mgn_mp_edge(None, None, None, None, None, None, C.byref(mlp), None, None, 0, 0, None) == 0
     assert lib.mgn_mp_node(None, None, None, C.byref(mlp), None, 0, None) == 0
+    # backward of the attention option: same conventions
+    assert lib.mgn_train_attn_edge_bwd(p, p, p, p, p, None, p, p, 1 << 31, None) == -1
+    assert b"mgn_train_attn_edge_bwd" in lib.mgn_last_error()
+    assert lib.mgn_train_attn_edge_bwd(None, p, p, p, p, None, p, p, 10, None) == -1
+    assert lib.mgn_train_attn_alpha_bwd(p, p, p, None, 10, None) == -1
+    assert lib.mgn_train_attn_alpha_bwd(p, p, p, p, 1 << 31, None) == -1
+    assert lib.mgn_train_attn_node_grad(p, p, None, None, p, p, 0, 10, None) == -1
+    assert lib.mgn_train_attn_edge_bwd(None, None, None, None, None, None, None, None, 0, None) == 0
+    assert lib.mgn_train_attn_alpha_bwd(None, None, None, None, 0, None) == 0
+    assert lib.mgn_train_attn_node_grad(None, None, None, None, None, None, 0, 0, None) == 0
