@@ -318,3 +318,60 @@ def test_options_loss_grads_golden(tag, att, ratio, csteps):
     for k in d.files:
         if k.startswith(pre):
             assert rel_l2(grads[k[len(pre):]], torch.from_numpy(d[k])) < 5e-3, k
+
+
+def test_attention_backward_entry_points_vs_torch():
+    """The three kernels behind the attention backward, each against the same expression in torch (fp64): the per-edge
+    weight gradient and message gradient, the per-receiver quotient rule with the reference's in-degree factor and the
+    clamp at 1e-6 (one receiver has a negative sum), and the two node-gradient sums (receiver CSR, sender view)."""
+    from gnn_amd import ops
+    gen = torch.Generator().manual_seed(2)
+    n, e = 70, 600
+    rcv = torch.sort(torch.randint(0, n - 5, (e,), generator=gen)).values          # CSR order; the last nodes receive nothing
+    snd = torch.randint(0, n, (e,), generator=gen)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    rowptr[1:] = torch.cumsum(torch.bincount(rcv, minlength=n), 0)
+    A = torch.randn(n, 128, generator=gen, dtype=torch.float64) * 0.3
+    A[int(rcv[0])] = -A[int(rcv[0])].abs() * 3                                      # a receiver whose alphas sum below the clamp
+    A[snd[rcv == rcv[0]]] = A[snd[rcv == rcv[0]]].abs()
+    ga = torch.randn(n, 128, generator=gen, dtype=torch.float64)
+    e_in, e_out = torch.randn(e, 128, generator=gen, dtype=torch.float64), torch.randn(e, 128, generator=gen, dtype=torch.float64)
+    g_e = torch.randn(e, 128, generator=gen, dtype=torch.float64)
+    d32 = lambda t: t.to(torch.float32).to(DEV)
+    i32 = lambda t: t.to(torch.int32).to(DEV)
+    # forward weights with the library, as the backward sees them
+    alpha, wts = torch.empty(e, device=DEV), torch.empty(e, device=DEV)
+    ops.edge_attention(d32(A), i32(rowptr), i32(snd), i32(rcv), alpha, wts)
+    dot = (A[snd] * A[rcv]).sum(-1)
+    al = torch.where(dot > 0, dot, 0.01 * dot)
+    S = torch.zeros(n, dtype=torch.float64).index_add_(0, rcv, al)
+    assert float(S[int(rcv[0])]) < 1e-6 and rel_l2(alpha, al) < 1e-5
+    # 1. per edge
+    gw, gm = torch.empty(e, device=DEV), torch.empty(e, 128, device=DEV)
+    ops.train_attn_edge_bwd(d32(ga), i32(rcv), d32(e_out), d32(e_in), wts, d32(g_e), gw, gm)
+    w64 = wts.double().cpu()
+    assert rel_l2(gw, (ga[rcv] * (e_out - e_in)).sum(-1)) < 1e-5
+    assert rel_l2(gm, g_e + w64[:, None] * ga[rcv]) < 1e-5
+    ops.train_attn_edge_bwd(d32(ga), i32(rcv), d32(e_out), d32(e_in), wts, None, gw, gm)
+    assert rel_l2(gm, w64[:, None] * ga[rcv]) < 1e-5
+    # 2. per receiver: autograd of the reference's expression (core/meshgraphnet.py:104-107) in fp64
+    alr = al.clone().requires_grad_(True)
+    den = torch.zeros(n, dtype=torch.float64).scatter_add_(0, rcv, alr)
+    den[rcv] = den[rcv].clamp(min=1e-6)
+    gw64 = gw.double().cpu()
+    ((alr / den[rcv]) * gw64).sum().backward()
+    ref_gdot = alr.grad * torch.where(al > 0, 1.0, 0.01)
+    gdot = torch.empty(e, device=DEV)
+    ops.train_attn_alpha_bwd(i32(rowptr), alpha, gw, gdot)
+    assert rel_l2(gdot, ref_gdot) < 1e-5, rel_l2(gdot, ref_gdot)
+    # 3. node gradients: d<a_s, a_r>/da_r = a_s (receiver side), /da_s = a_r (sender side)
+    gd64 = gdot.double().cpu()
+    ref = torch.zeros(n, 128, dtype=torch.float64).index_add_(0, rcv, gd64[:, None] * A[snd])
+    ref.index_add_(0, snd, gd64[:, None] * A[rcv])
+    order = torch.argsort(snd, stable=True)
+    s_rowptr = torch.zeros(n + 1, dtype=torch.int64)
+    s_rowptr[1:] = torch.cumsum(torch.bincount(snd, minlength=n), 0)
+    out = torch.full((n, 128), float("nan"), device=DEV)
+    ops.train_attn_node_grad(d32(A), i32(rowptr), None, i32(snd), gdot, out, False)
+    ops.train_attn_node_grad(d32(A), i32(s_rowptr), i32(order), i32(rcv), gdot, out, True)
+    assert rel_l2(out, ref) < 1e-5, rel_l2(out, ref)
