@@ -185,6 +185,10 @@ def rollout_batched(model, trajectories, progress: bool = False):
     blocks instead of one per trajectory and step; with statistics that no longer accumulate
     the per-trajectory results are identical to separate :func:`rollout` calls."""
     trajectories = list(trajectories)
+    if getattr(model, "sample_ratio", 0) > 0 and len(trajectories) > 1:
+        # the coarse graph is built from the coordinates of the union: sampling and nearest neighbours would tie
+        # the trajectories (which share their mesh coordinates) to one another
+        raise NotImplementedError("rollout_batched: not with the coarse multiscale branch (sample_ratio > 0)")
     n_frames = len(trajectories[0])
     if any(len(tr) != n_frames for tr in trajectories):
         raise ValueError("rollout_batched: trajectories must have the same number of frames")

@@ -375,3 +375,21 @@ def test_attention_backward_entry_points_vs_torch():
     ops.train_attn_node_grad(d32(A), i32(rowptr), None, i32(snd), gdot, out, False)
     ops.train_attn_node_grad(d32(A), i32(s_rowptr), i32(order), i32(rcv), gdot, out, True)
     assert rel_l2(out, ref) < 1e-5, rel_l2(out, ref)
+
+
+def test_batched_rollout_with_options():
+    """Block-diagonal batches: attention stays per trajectory (its sums run over a receiver's own in-edges), so a batch
+    equals the separate rollouts; the coarse branch would tie the trajectories together and is refused."""
+    import gnn_amd
+    from gnn_amd.rollout import rollout, rollout_batched
+    cfg = O.OracleConfig(process_steps=2, attention=True)
+    model = build(cfg, O.init_state_dict(cfg, 3))
+    freeze_to(model, cfg, O.make_norms(cfg))
+    trajs = [gnn_amd.synthetic_frames(9, 6, n_frames=5, seed=s) for s in (1, 2, 3)]
+    both = rollout_batched(model, trajs)
+    for tr, res in zip(trajs, both):
+        assert rel_l2(res["pred"], rollout(model, tr)["pred"]) < 1e-6
+    cfg2 = O.OracleConfig(process_steps=1, sample_ratio=0.5, coarse_process_steps=1)
+    model2 = build(cfg2, O.init_state_dict(cfg2, 3))
+    with pytest.raises(NotImplementedError):
+        rollout_batched(model2, trajs)
