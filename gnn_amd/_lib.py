@@ -75,6 +75,7 @@ SIGNATURES = {
     "mgn_train_loss_bwd": (C.c_int, [_P, _P, _P, _P, _I32, _I64, _P, _P]),
     "mgn_train_edge_bwd": (C.c_int, [_P] * 19 + [_I64, _I64, _P]),
     "mgn_adam_step": (C.c_int, [_P, _I32, _F, _F, _F, _F, _F, _I64, _P]),
+    "mgn_segment_sum_weighted": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
     "mgn_train_attn_edge_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_train_attn_alpha_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _P]),
     "mgn_train_attn_node_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I64, _P]),

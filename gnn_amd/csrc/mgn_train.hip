@@ -824,11 +824,26 @@ __global__ __launch_bounds__(NT) void segment_sum_kernel(const float* __restrict
     }
 }
 
+// the same with a weight per source row (rows in segment order): out[n] = sum of weight[k] * src[k] (attention option,
+// forward of the path that keeps every Linear as its own launch)
+__global__ __launch_bounds__(NT) void segment_sum_weighted_kernel(const float* __restrict__ src, const int* __restrict__ rowptr,
+                                                                  const float* __restrict__ weight, float* __restrict__ out,
+                                                                  long long n_seg) {
+    const int sq = threadIdx.x & 31;
+    for (long long n = (long long)blockIdx.x * 8 + (threadIdx.x >> 5); n < n_seg; n += (long long)gridDim.x * 8) {
+        const int k0 = rowptr[n], k1 = rowptr[n + 1];
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k = k0; k < k1; ++k) s += *(const f32x4*)(src + (size_t)k * H + 4 * sq) * weight[k];
+        *(f32x4*)(out + n * H + 4 * sq) = s;
+    }
+}
+
 // ------------------------------------------------------------------------ attention option, backward
 // Forward (core/meshgraphnet.py:100-108): alpha_e = leaky_relu(<a[s_e], a[r_e]>), w_e = alpha_e / max(sum of alpha over
 // the in-edges of r_e, 1e-6), aggr[r] = sum of w_e * m_e with m_e the block's pre-residual edge output.
 //
-// Per edge (32 lanes, 16 bytes of each row per lane): gw_e = <g_aggr[r_e], m_e> with m_e = e_out - e_in, and the
+// Per edge (32 lanes, 16 bytes of each row per lane): gw_e = <g_aggr[r_e], m_e> with m_e = e_out - e_in (e_out alone when
+// the caller kept m_e itself and passes no e_in), and the
 // gradient reaching m_e from the sum, w_e * g_aggr[r_e], added to the upstream gradient of e_out (g_e_in, or nothing).
 __global__ __launch_bounds__(NT) void attn_edge_bwd_kernel(const float* __restrict__ g_aggr, const int* __restrict__ recv,
                                                            const float* __restrict__ e_out, const float* __restrict__ e_in,
@@ -837,7 +852,8 @@ __global__ __launch_bounds__(NT) void attn_edge_bwd_kernel(const float* __restri
     const int l = threadIdx.x & 31;
     for (long long e = ((long long)blockIdx.x * NT + threadIdx.x) >> 5; e < n_edges; e += ((long long)gridDim.x * NT) >> 5) {
         const f32x4 ga = *(const f32x4*)(g_aggr + (size_t)recv[e] * H + 4 * l);
-        const f32x4 m = *(const f32x4*)(e_out + (size_t)e * H + 4 * l) - *(const f32x4*)(e_in + (size_t)e * H + 4 * l);
+        f32x4 m = *(const f32x4*)(e_out + (size_t)e * H + 4 * l);
+        if (e_in) m -= *(const f32x4*)(e_in + (size_t)e * H + 4 * l);
         float d = (ga[0] * m[0] + ga[1] * m[1]) + (ga[2] * m[2] + ga[3] * m[3]);
 #pragma unroll
         for (int k = 16; k >= 1; k >>= 1) d += __shfl_xor(d, k, 32);
@@ -1129,12 +1145,22 @@ extern "C" int mgn_segment_sum(const float* src, const int32_t* rowptr, const in
     return check_launch("mgn_segment_sum");
 }
 
+extern "C" int mgn_segment_sum_weighted(const float* src, const int32_t* rowptr, const float* weight, float* out,
+                                        int64_t n_segments, void* stream) {
+    MGN_REQUIRE(n_segments >= 0 && n_segments < (1ll << 31), "mgn_segment_sum_weighted");
+    if (n_segments == 0) return 0;
+    MGN_REQUIRE(src && rowptr && weight && out, "mgn_segment_sum_weighted");
+    hipLaunchKernelGGL(segment_sum_weighted_kernel, dim3(stream_grid(n_segments, 8)), dim3(NT), 0, (hipStream_t)stream, src,
+                       rowptr, weight, out, (long long)n_segments);
+    return check_launch("mgn_segment_sum_weighted");
+}
+
 extern "C" int mgn_train_attn_edge_bwd(const float* g_aggr, const int32_t* csr_recv, const float* e_out, const float* e_in,
                                        const float* edge_weight, const float* g_e_in, float* g_weight, float* g_e_out,
                                        int64_t n_edges, void* stream) {
     MGN_REQUIRE(n_edges >= 0 && n_edges < (1ll << 31), "mgn_train_attn_edge_bwd");
     if (n_edges == 0) return 0;
-    MGN_REQUIRE(g_aggr && csr_recv && e_out && e_in && edge_weight && g_weight && g_e_out, "mgn_train_attn_edge_bwd");
+    MGN_REQUIRE(g_aggr && csr_recv && e_out && edge_weight && g_weight && g_e_out, "mgn_train_attn_edge_bwd");
     hipLaunchKernelGGL(attn_edge_bwd_kernel, dim3(stream_grid(n_edges * 32, NT)), dim3(NT), 0, (hipStream_t)stream, g_aggr,
                        csr_recv, e_out, e_in, edge_weight, g_e_in, g_weight, g_e_out, (long long)n_edges);
     return check_launch("mgn_train_attn_edge_bwd");

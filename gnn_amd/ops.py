@@ -656,10 +656,10 @@ def train_edge_bwd(e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, 
 @_timed_op
 def train_attn_edge_bwd(g_aggr, recv, e_out, e_in, edge_weight, g_e_in, g_weight, g_e_out):
     """Attention option: gradient of the message weights [E] and of the edge MLP's (pre-residual) output [E,H]."""
-    e, n = e_in.shape[0], g_aggr.shape[0]
+    e, n = e_out.shape[0], g_aggr.shape[0]
     rc = _lib.lib().mgn_train_attn_edge_bwd(
         _dev(g_aggr, torch.float32, (n, H), "g_aggr"), _dev(recv, torch.int32, (e,), "recv"), _rows128(e_out, "e_out", e),
-        _rows128(e_in, "e_in", e), _dev(edge_weight, torch.float32, (e,), "edge_weight"), _opt(g_e_in, torch.float32, (e, H), "g_e_in"),
+        _opt(e_in, torch.float32, (e, H), "e_in"), _dev(edge_weight, torch.float32, (e,), "edge_weight"), _opt(g_e_in, torch.float32, (e, H), "g_e_in"),
         _dev(g_weight, torch.float32, (e,), "g_weight"), _rows128(g_e_out, "g_e_out", e), e, _stream())
     _lib.check(rc, "mgn_train_attn_edge_bwd")
 
@@ -691,6 +691,14 @@ def segment_sum(src, rowptr, out, order=None):
     rc = _lib.lib().mgn_segment_sum(_dev(src, torch.float32, (None, H), "src"), C.c_void_p(rowptr.data_ptr()),
                                     _opt(order, torch.int32, (None,), "order"), _rows128(out, "out"), n, _stream())
     _lib.check(rc, "mgn_segment_sum")
+
+
+@_timed_op
+def segment_sum_weighted(src, rowptr, weight, out):
+    n, e = out.shape[0], src.shape[0]
+    rc = _lib.lib().mgn_segment_sum_weighted(_rows128(src, "src"), _dev(rowptr, torch.int32, (n + 1,), "rowptr"),
+                                             _dev(weight, torch.float32, (e,), "weight"), _rows128(out, "out"), n, _stream())
+    _lib.check(rc, "mgn_segment_sum_weighted")
 
 
 @_timed_op

@@ -72,9 +72,8 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
         raise RuntimeError("the training kernels run on the GPU only")
     if model.node_out_dim != 3:
         raise RuntimeError("loss: node_out_dim must be 3")
-    if model.attention and (not fused or halo is not None):
-        raise NotImplementedError("loss() with the attention option runs on the fused default matrix path (MGN_MATMUL=f16x2, "
-                                  "MGN_TRAIN_FUSED unset) of an unpartitioned model only")
+    if model.attention and halo is not None:
+        raise NotImplementedError("loss() with the attention option: not on a partitioned model")
     f32 = model._f32
     topo = halo.topology if halo is not None else model.topology(graph)
     n_loc, e, T = topo.num_nodes, topo.num_edges, model.time_dim
@@ -160,16 +159,22 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
                 ops.train_linear_fwd(el, w0, 2 * H, h1e, p=ps, idx_p=topo.sender, q=pr, idx_q=topo.recv, relu=True)
                 ops.train_linear_fwd(h1e, em[2].weight.detach(), 0, ve, bias=em[2].bias.detach(), relu=True)
                 e_next = None if last else _empty(e, dev)      # the edge latents after the last block are unused
+                if att is not None:
+                    eprime = _empty(e, dev)                    # the messages themselves are kept for the weights' backward
                 ops.train_ln_fwd(ve, em[4].weight.detach(), em[4].bias.detach(), y=eprime,
                                  res=None if last else el, yres=e_next)
                 aggr = _empty(n, dev)
-                ops.segment_sum(eprime, rowptr, aggr)
+                if att is None:
+                    ops.segment_sum(eprime, rowptr, aggr)
+                else:
+                    ops.segment_sum_weighted(eprime, rowptr, att[2], aggr)
             h1n, vn, x_next = _empty(n, dev), _empty(n, dev), _empty(n, dev)
             ops.train_linear_fwd(x, nm[0].weight.detach(), 0, h1n, b=aggr, koff_b=H, bias=nm[0].bias.detach(), relu=True)
             ops.train_linear_fwd(h1n, nm[2].weight.detach(), 0, vn, bias=nm[2].bias.detach(), relu=True)
             ops.train_ln_fwd(vn, nm[4].weight.detach(), nm[4].bias.detach(), res=x, yres=x_next)
+            # with attention: the projected rows, alpha, the weights and the messages (fused path: as e_next - el)
             layers.append((x, el, h1e, ve, aggr, h1n, vn, ps if fused else None, pr if fused else None,
-                           None if att is None else att + (e_next,)))
+                           None if att is None else att + ((e_next, el) if fused else (eprime, None))))
             x, el = x_next, e_next
 
         return x, layers
@@ -284,19 +289,23 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
             if att is not None:
                 # aggr = sum of w_e * m_e with m_e = e_next - el: the weights' gradient goes back to attn_lin and the
                 # node latents; m_e receives w_e * gaggr[r_e] on top of what reaches e_next
-                a_proj, alpha, wts, e_next = att
+                a_proj, alpha, wts, m_out, m_in = att
                 gw, gdot = torch.empty(e, dtype=torch.float32, device=dev), torch.empty(e, dtype=torch.float32, device=dev)
                 ge_m, ga = _empty(e, dev), _empty(n, dev)
-                ops.train_attn_edge_bwd(gaggr, topo.recv, e_next, el, wts, ge, gw, ge_m)
+                ops.train_attn_edge_bwd(gaggr, topo.recv, m_out, m_in, wts, ge, gw, ge_m)
                 ops.train_attn_alpha_bwd(rowptr, alpha, gw, gdot)
                 ops.train_attn_node_grad(a_proj, rowptr, None, topo.sender, gdot, ga, False)
                 ops.train_attn_node_grad(a_proj, s_rowptr, s_order, topo.recv, gdot, ga, True)
                 dwa, dba = g_like(blk.attn_lin.weight), vec()
                 ops.train_linear_bwd(ga, scratch, a=x, w=blk.attn_lin.weight.detach(), res=gx, ga=gx, dw=dwa, db=dba)
                 grads[pre + "attn_lin.weight"], grads[pre + "attn_lin.bias"] = dwa, dba
-                ops.train_edge_bwd(el, ge_m, torch.zeros_like(gaggr), ps_b, pr_b, topo.sender, topo.recv, rowptr,
-                                   em[0].weight.detach(), em[2].weight.detach(), em[2].bias.detach(), em[4].weight.detach(),
-                                   g1e, dpr, dw, db, dg, dbt, scratch)
+                if saved["fused"]:
+                    ops.train_edge_bwd(el, ge_m, torch.zeros_like(gaggr), ps_b, pr_b, topo.sender, topo.recv, rowptr,
+                                       em[0].weight.detach(), em[2].weight.detach(), em[2].bias.detach(), em[4].weight.detach(),
+                                       g1e, dpr, dw, db, dg, dbt, scratch)
+                else:
+                    ops.train_ln_bwd(ve, em[4].weight.detach(), g2e, dg, dbt, scratch, g=ge_m, relu_mask=True)
+                    ops.train_linear_bwd(g2e, scratch, a=h1e, w=em[2].weight.detach(), mask=h1e, ga=g1e, dw=dw, db=db)
             elif saved["fused"]:
                 ops.train_edge_bwd(el, ge, gaggr, ps_b, pr_b, topo.sender, topo.recv, rowptr, em[0].weight.detach(),
                                    em[2].weight.detach(), em[2].bias.detach(), em[4].weight.detach(), g1e, dpr, dw, db, dg, dbt,

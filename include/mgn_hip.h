@@ -365,9 +365,14 @@ int mgn_train_loss_fwd(const float* decoded, const float* target_norm, const flo
 int mgn_train_loss_bwd(const float* decoded, const float* target_norm, const float* node_type, const float* grad3,
                        int32_t time_dim, int64_t n_nodes, float* gdecoded, void* stream);
 
+/* out[n] = sum over k in [rowptr[n], rowptr[n+1]) of weight[k] * src[k]: the weighted receiver sum of the attention option
+ * (core/meshgraphnet.py:108, :113) for callers that hold the messages as a tensor. */
+int mgn_segment_sum_weighted(const float* src /*[E][H]*/, const int32_t* rowptr, const float* weight /*[E]*/,
+                             float* out /*[N][H]*/, int64_t n_segments, void* stream);
+
 /* Backward of the attention option (core/meshgraphnet.py:100-108; forward: mgn_edge_attention + mgn_mp_edge_weighted).
  * mgn_train_attn_edge_bwd: per edge, g_weight[j] = <g_aggr[recv[j]], e_out[j] - e_in[j]> (the block's pre-residual
- * edge output is e_out - e_in) and g_e_out[j] = g_e_in[j] (or 0 when NULL) + edge_weight[j] * g_aggr[recv[j]]: the
+ * edge output is e_out - e_in; with e_in NULL, e_out is taken to be that output itself) and g_e_out[j] = g_e_in[j] (or 0 when NULL) + edge_weight[j] * g_aggr[recv[j]]: the
  * gradient that reaches the edge MLP's output; pass g_e_out to mgn_train_edge_bwd with a zero g_aggr.
  * mgn_train_attn_alpha_bwd: per receiver, g_dot = gradient wrt <a[s], a[r]> from g_weight: g_weight / D minus
  * in-degree * (sum of g_weight * alpha) / D^2 (nothing through a sum clamped at 1e-6), times the leaky slope 1 / 0.01 by
@@ -376,7 +381,7 @@ int mgn_train_loss_bwd(const float* decoded, const float* target_norm, const flo
  * mgn_train_attn_node_grad: out[v] (+)= sum over v's edge list of g_dot[j] * a_proj[other[j]]; called once with the
  * receiver CSR (order NULL, other = csr_sender) and once with the sender view (order = edges by sender,
  * other = csr_recv, accumulate 1): the gradient of attn_lin's output, which then goes through a Linear backward. */
-int mgn_train_attn_edge_bwd(const float* g_aggr /*[N][H]*/, const int32_t* csr_recv, const float* e_out, const float* e_in,
+int mgn_train_attn_edge_bwd(const float* g_aggr /*[N][H]*/, const int32_t* csr_recv, const float* e_out, const float* e_in /*or NULL*/,
                             const float* edge_weight /*[E]*/, const float* g_e_in /*[E][H] or NULL*/,
                             float* g_weight /*[E]*/, float* g_e_out /*[E][H]*/, int64_t n_edges, void* stream);
 int mgn_train_attn_alpha_bwd(const int32_t* rowptr, const float* alpha /*[E]*/, const float* g_weight /*[E]*/,

@@ -243,14 +243,21 @@ def test_multiscale_training_loop_reduces_the_loss():
 
 
 @pytest.mark.parametrize("nx,ny,steps,csteps,ratio", [(14, 9, 2, 0, 0.0), (24, 15, 3, 0, 0.0), (16, 10, 2, 1, 0.4)])
-def test_attention_loss_and_gradients_vs_oracle(nx, ny, steps, csteps, ratio):
-    """``loss()`` + backward with the attention option (alone and with the coarse branch) against the oracle's autograd,
+def test_attention_loss_and_gradients_vs_oracle(nx, ny, steps, csteps, ratio, matmul_mode, monkeypatch):
+    """``loss()`` + backward with the attention option (alone and with the coarse branch), in the three matrix modes (the
+    default one with the fused edge update and, for the first case, also with every Linear as its own launch) against the oracle's autograd,
     which runs the reference's own sequence of tensor operations (:100-108), including the in-place clamp through the
     repeated receiver index, whose autograd hands each receiver's denominator gradient to every in-edge.  Loss to 1e-5;
     all gradients, those of ``attn_lin`` included, within the same bounds as the multiscale test."""
-    from test_gpu_training import FixedStats
     cfg = O.OracleConfig(process_steps=steps, sample_ratio=ratio, coarse_process_steps=csteps, attention=True)
     sd = O.init_state_dict(cfg, 7)
+    for fused_env in ["1"] + (["0"] if matmul_mode == "f16x2" and nx == 14 else []):
+        monkeypatch.setenv("MGN_TRAIN_FUSED", fused_env)
+        _attention_case(cfg, sd, nx, ny, steps)
+
+
+def _attention_case(cfg, sd, nx, ny, steps):
+    from test_gpu_training import FixedStats
     model = build(cfg, sd).train()
     model.coarse_start = 2
     norms = O.make_norms(cfg)
