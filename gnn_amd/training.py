@@ -72,8 +72,6 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
         raise RuntimeError("the training kernels run on the GPU only")
     if model.node_out_dim != 3:
         raise RuntimeError("loss: node_out_dim must be 3")
-    if model.attention and halo is not None:
-        raise NotImplementedError("loss() with the attention option: not on a partitioned model")
     f32 = model._f32
     topo = halo.topology if halo is not None else model.topology(graph)
     n_loc, e, T = topo.num_nodes, topo.num_edges, model.time_dim
@@ -136,9 +134,11 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
             att = None
             if blk.attention:
                 # message weights from the block's input node latents (core/meshgraphnet.py:100-107)
-                a_proj = _empty(n, dev)
+                a_proj = _empty(n_loc, dev)
                 alpha, wts = torch.empty(e, dtype=torch.float32, device=dev), torch.empty(e, dtype=torch.float32, device=dev)
-                ops.train_linear_fwd(x, blk.attn_lin.weight.detach(), 0, a_proj, bias=blk.attn_lin.bias.detach())
+                ops.train_linear_fwd(x, blk.attn_lin.weight.detach(), 0, a_proj[:n], bias=blk.attn_lin.bias.detach())
+                if halo is not None:
+                    halo.exchange_rows(a_proj)                       # projected rows of the halo senders
                 ops.edge_attention(a_proj, topo.rowptr, topo.sender, topo.recv, alpha, wts)
                 att = (a_proj, alpha, wts)
             if fused:
@@ -291,13 +291,17 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
                 # node latents; m_e receives w_e * gaggr[r_e] on top of what reaches e_next
                 a_proj, alpha, wts, m_out, m_in = att
                 gw, gdot = torch.empty(e, dtype=torch.float32, device=dev), torch.empty(e, dtype=torch.float32, device=dev)
-                ge_m, ga = _empty(e, dev), _empty(n, dev)
+                ge_m, ga_loc = _empty(e, dev), _empty(n_loc, dev)
                 ops.train_attn_edge_bwd(gaggr, topo.recv, m_out, m_in, wts, ge, gw, ge_m)
                 ops.train_attn_alpha_bwd(rowptr, alpha, gw, gdot)
-                ops.train_attn_node_grad(a_proj, rowptr, None, topo.sender, gdot, ga, False)
-                ops.train_attn_node_grad(a_proj, s_rowptr, s_order, topo.recv, gdot, ga, True)
+                ops.train_attn_node_grad(a_proj, rowptr, None, topo.sender, gdot, ga_loc[:n], False)     # as receivers (owned)
+                if n_loc > n:
+                    ga_loc[n:].zero_()
+                ops.train_attn_node_grad(a_proj, s_rowptr, s_order, topo.recv, gdot, ga_loc, True)      # as senders (owned + halo)
+                if halo is not None:
+                    halo.return_rows(ga_loc)                         # the halo senders' sums go back to their owners
                 dwa, dba = g_like(blk.attn_lin.weight), vec()
-                ops.train_linear_bwd(ga, scratch, a=x, w=blk.attn_lin.weight.detach(), res=gx, ga=gx, dw=dwa, db=dba)
+                ops.train_linear_bwd(ga_loc[:n], scratch, a=x, w=blk.attn_lin.weight.detach(), res=gx, ga=gx, dw=dwa, db=dba)
                 grads[pre + "attn_lin.weight"], grads[pre + "attn_lin.bias"] = dwa, dba
                 if saved["fused"]:
                     ops.train_edge_bwd(el, ge_m, torch.zeros_like(gaggr), ps_b, pr_b, topo.sender, topo.recv, rowptr,

@@ -157,15 +157,21 @@ def test_partitioned_rollout_matches_single_gpu(world, nx, ny, attention):
     assert rel_l2(out, ref) < 1e-6, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_partitioned_training_step_matches_single_gpu(world):
+@pytest.mark.parametrize("world,attention", [(2, False), (3, False), (3, True)])
+def test_partitioned_training_step_matches_single_gpu(world, attention):
     """loss + backward on a mesh split over ranks: forward halo of the sender projections, reverse
     halo of their gradients, one all-reduce of the loss and of the parameter gradients.  Every rank
     must end with the single-GPU loss and gradients (sums are grouped differently: 1e-5)."""
     from gnn_amd import partition
     from gnn_amd.graph import MeshGraph
-    from test_gpu_model import build_model
-    cfg = O.OracleConfig(process_steps=3)
+    if attention:       # the attn_lin rows of the halo senders travel forward, their gradients back
+        from test_gpu_options import build
+
+        def build_model(cfg, sd):
+            return build(cfg, sd).train()
+    else:
+        from test_gpu_model import build_model
+    cfg = O.OracleConfig(process_steps=3, attention=attention)
     sd = O.init_state_dict(cfg, 11)
     g = O.synthetic_graph(40, 33, seed=8)
     n = g["mesh_pos"].shape[0]
