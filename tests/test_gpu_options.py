@@ -400,3 +400,34 @@ def test_batched_rollout_with_options():
     model2 = build(cfg2, O.init_state_dict(cfg2, 3))
     with pytest.raises(NotImplementedError):
         rollout_batched(model2, trajs)
+
+
+@pytest.mark.parametrize("tag,att,ratio,csteps", [("plain", False, 0.0, 0)] + CASES)
+def test_predict_on_an_irregular_graph_vs_oracle(tag, att, ratio, csteps, matmul_mode):
+    """Whole-model parity off the mesh: a directed random graph with a hub of in-degree 400 (its sum spans a dozen edge
+    tiles), nodes without in-edges, nodes without out-edges, duplicate edges and self-loops, edges in random order;
+    plain model and the two options, every matrix path, at equal statistics."""
+    gen = torch.Generator().manual_seed(12)
+    n, e = 700, 5000
+    snd, rcv = torch.randint(0, n - 30, (e,), generator=gen), torch.randint(0, n - 60, (e,), generator=gen)
+    rcv[:400] = 11                                                  # hub
+    snd[400:420], rcv[400:420] = snd[420:440], rcv[420:440]         # duplicates
+    snd[440:450] = rcv[440:450]                                     # self-loops
+    perm = torch.randperm(e, generator=gen)
+    g = O.synthetic_graph(34, 19, seed=2)                           # 700 nodes: fields and coordinates from the mesh
+    assert g["mesh_pos"].shape[0] == n
+    g["edge_index"] = torch.stack([snd[perm], rcv[perm]])
+    cfg = O.OracleConfig(process_steps=3, attention=att, sample_ratio=ratio, coarse_process_steps=csteps)
+    sd = O.init_state_dict(cfg, 9)
+    model = build(cfg, sd)
+    norms = O.make_norms(cfg)
+    norms["output"].normalize(1e-3 * torch.randn(1, n, 3, generator=gen))
+    ref_f = O.forward(sd, cfg, norms, g, coarse_start=4)
+    freeze_to(model, cfg, norms)
+    model.coarse_start = 4
+    out_f = model.forward(graph_to(g, DEV))
+    ref = O.predict(sd, cfg, norms, g, coarse_start=4)
+    freeze_to(model, cfg, norms)
+    out = model.predict(graph_to(g, DEV))
+    print("%s irregular graph: forward %.3e predict %.3e" % (tag, rel_l2(out_f, ref_f), rel_l2(out, ref)))
+    assert rel_l2(out_f, ref_f) < TOL and rel_l2(out, ref) < TOL
