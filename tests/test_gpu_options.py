@@ -431,3 +431,44 @@ def test_predict_on_an_irregular_graph_vs_oracle(tag, att, ratio, csteps, matmul
     out = model.predict(graph_to(g, DEV))
     print("%s irregular graph: forward %.3e predict %.3e" % (tag, rel_l2(out_f, ref_f), rel_l2(out, ref)))
     assert rel_l2(out_f, ref_f) < TOL and rel_l2(out, ref) < TOL
+
+
+@pytest.mark.parametrize("tag,att,ratio,csteps", [("plain", False, 0.0, 0), ("both", True, 0.4, 1)])
+def test_loss_and_gradients_on_an_irregular_graph_vs_oracle(tag, att, ratio, csteps, matmul_mode):
+    """``loss()`` + backward off the mesh (the graph of the test above: hub of in-degree 400, nodes without in- or
+    out-edges, duplicates, self-loops, random edge order): the receiver sums of the fused edge backward span many tiles,
+    the sender view has empty and long lists.  Bounds: 1e-2 / 2e-2 (measured: 2e-6 for the plain model; with both options
+    1.4e-3, and 4.8e-3 on one ``attn_lin.bias`` in the default matrix mode, fused or not -- the hub's weights turn one
+    flipped ReLU into a visible change of that gradient)."""
+    from test_gpu_training import FixedStats
+    gen = torch.Generator().manual_seed(12)
+    n, e = 700, 5000
+    snd, rcv = torch.randint(0, n - 30, (e,), generator=gen), torch.randint(0, n - 60, (e,), generator=gen)
+    rcv[:400] = 11
+    snd[400:420], rcv[400:420] = snd[420:440], rcv[420:440]
+    snd[440:450] = rcv[440:450]
+    perm = torch.randperm(e, generator=gen)
+    g = O.synthetic_graph(34, 19, seed=2, with_target=True)
+    g["edge_index"] = torch.stack([snd[perm], rcv[perm]])
+    cfg = O.OracleConfig(process_steps=2, attention=att, sample_ratio=ratio, coarse_process_steps=csteps)
+    sd = O.init_state_dict(cfg, 9)
+    model = build(cfg, sd).train()
+    model.coarse_start = 4
+    norms = O.make_norms(cfg)
+    l32, g32 = _oracle_loss_and_grads(cfg, sd, norms, g, 4, torch.float32)
+    freeze_to(model, cfg, norms)
+    fixed = {k: FixedStats(v, torch.float64) for k, v in norms.items()}
+    _, g64 = _oracle_loss_and_grads(cfg, sd, fixed, g, 4, torch.float64)
+    out = model.loss(graph_to(g, DEV))
+    out[0].backward()
+    for c in range(4):
+        assert abs(float(out[c].detach()) - l32[c]) <= 1e-5 * abs(l32[c]), (c, float(out[c].detach()), l32[c])
+    worst = ("", 0.0, 0.0)
+    for k, p in model.named_parameters():
+        if g32[k] is None:
+            assert p.grad is None or not p.grad.any(), k
+            continue
+        r32, r64 = rel_l2(p.grad, g32[k]), rel_l2(p.grad.double(), g64[k])
+        assert r32 < 1e-2 and r64 < 2e-2, (k, r32, r64)
+        worst = max(worst, (k, r32, r64), key=lambda t: t[2])
+    print("%s irregular graph, worst gradient rel-L2 (fp32 reference, fp64 reference): %s %.2e %.2e" % ((tag,) + worst))
