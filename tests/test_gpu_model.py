@@ -312,6 +312,44 @@ def test_full_size_mesh_matches_oracle_on_a_crop():
                   ref[:, near] - torch.cat([gc["world_pos"], gc["phi"]], -1)[near]) > 1e-3
 
 
+def test_full_size_mesh_properties():
+    """Size-independent properties at the benchmark's full size (1000 x 1000 nodes, 5 992 002 edges, 15 blocks), frozen
+    statistics: two runs are bit-identical; renumbering the nodes (Morton order) and undoing it on the output changes
+    the normalised deltas by 1e-5 at most (only the order of the summands in the receiver sums differs); and the
+    Dirichlet columns of the prediction equal the current state exactly (core/meshgraphnet.py:309-315)."""
+    import gnn_amd
+    from gnn_amd import reorder as R
+    cfg = O.OracleConfig(process_steps=15)
+    sd = O.init_state_dict(cfg, 7)
+    g = gnn_amd.synthetic_frames(999, 999, seed=0)[0]
+    n = g["mesh_pos"].shape[0]
+    model = build_model(cfg, sd)
+    small = O.synthetic_graph(20, 12, seed=1)
+    norms = O.make_norms(cfg)
+    O.forward(sd, cfg, norms, small)                       # plausible statistics from a small mesh, frozen
+    norms["output"].normalize(1e-3 * torch.randn(1, 273, 3, generator=torch.Generator().manual_seed(4)))
+    for v in norms.values():
+        v.max_accumulations = 0
+    copy_norms_frozen(model, norms)
+    gd = g.to(DEV)
+    f1 = model.forward(gd).clone()
+    f2 = model.forward(gd)
+    assert torch.isfinite(f1).all() and torch.equal(f1, f2)
+    order = R.node_order(g, "morton")
+    gp = R.permute_frame(g, order)
+    fp = R.restore_nodes(model.forward(gp.to(DEV)).cpu(), order, dim=1)
+    assert rel_l2(fp, f1) < TOL, rel_l2(fp, f1)
+    pred = model.predict(gd).cpu()
+    cur = torch.cat([g["world_pos"], g["phi"]], -1)
+    checked = 0
+    for col, comp in ((1, 0), (2, 1), (3, 2)):
+        mask = g["node_type"][:, col] == 1
+        if bool(mask.any()):
+            assert torch.equal(pred[0, mask, comp], cur[mask, comp])
+            checked += 1
+    assert checked >= 2 and n == 1_000_000
+
+
 @pytest.mark.parametrize("method", ["rcm", "morton"])
 def test_rollout_with_locality_reordering(method):
     """A trajectory on a mesh with shuffled node ids: the rollout that renumbers the nodes first
