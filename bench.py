@@ -44,11 +44,11 @@ FLOP_PER_EDGE_EDGE_KERNEL = 2 * (128 * 128 + 128 * 128)    # 65536: what mp_edge
 BYTES_PER_EDGE_EDGE_KERNEL = 512 + 512 + 8                 # e in, e out, sender + receiver ids
 
 
-def pmc_traffic(kernel, edges):
+def pmc_traffic(kernel, edges, file="r02_pmc_traffic.json"):
     """HBM bytes per launch of `kernel` from the committed counter pass (FETCH_SIZE and WRITE_SIZE are
     collected in separate rocprofv3 --pmc runs, which a timed run cannot do itself); scales with the
     edge count, None when no pass for this kernel is on file."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", file)
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -182,7 +182,9 @@ def train_object(args, device):
         bytes_alg = (3 * 512 + 8) * e
         out["roofline"] = {"kernel": "train_edge_bwd_kernel", "bound": "hbm", "achieved": bytes_alg / t / 1e9,
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_alg / t / 1e9 / PEAK_HBM_GBS,
-                           "traffic": None, "avg_launch_ms": t * 1e3, "bytes_per_edge_algorithmic": 3 * 512 + 8}
+                           "traffic": pmc_traffic("train_edge_bwd_kernel", e, "r02_pmc_traffic_train.json"),
+                           "traffic_unit": "bytes per launch (rocprofv3 PMC passes, profiles/r02_pmc_traffic_train.json)",
+                           "avg_launch_ms": t * 1e3, "bytes_per_edge_algorithmic": 3 * 512 + 8}
     return out
 
 

@@ -13,5 +13,5 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         acc[(name[-40:], row["Counter_Name"])].append(float(row["Counter_Value"]))
         acc[(name[-40:], "~duration_us")].append((float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3)
 for (k, c), v in sorted(acc.items()):
-    if any(s in k for s in ("mp_", "encode", "decode")):
+    if any(s in k for s in ("mp_", "encode", "decode", "train_", "segment_sum")):
         print(f"{k:42s} {c:28s} n={len(v):3d} mean={sum(v) / len(v):.4g}")
