@@ -371,6 +371,11 @@ def test_attention_backward_entry_points_vs_torch():
     gdot = torch.empty(e, device=DEV)
     ops.train_attn_alpha_bwd(i32(rowptr), alpha, gw, gdot)
     assert rel_l2(gdot, ref_gdot) < 1e-5, rel_l2(gdot, ref_gdot)
+    # the weighted receiver sum of the unfused forward
+    agg = torch.full((n, 128), float("nan"), device=DEV)
+    ops.segment_sum_weighted(d32(e_out), i32(rowptr), wts, agg)
+    ref_agg = torch.zeros(n, 128, dtype=torch.float64).index_add_(0, rcv, w64[:, None] * e_out)
+    assert rel_l2(agg, ref_agg) < 1e-5 and float(agg[n - 1].abs().max()) == 0.0
     # 3. node gradients: d<a_s, a_r>/da_r = a_s (receiver side), /da_s = a_r (sender side)
     gd64 = gdot.double().cpu()
     ref = torch.zeros(n, 128, dtype=torch.float64).index_add_(0, rcv, gd64[:, None] * A[snd])
