@@ -81,6 +81,10 @@ SIGNATURES = {
     "mgn_train_attn_node_grad": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I64, _P]),
     "mgn_adam_hyper": (C.c_int, [_F, _F, _F, _F, _F, _I64, _P]),
     "mgn_adam_step_dev": (C.c_int, [_P, _I32, _P, _P]),
+    "mgn_halo_pack": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
+    "mgn_halo_unpack_add": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "mgn_halo_stage_state": (C.c_int, [_P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
+    "mgn_halo_unpack_state": (C.c_int, [_P, _I64, _P, _P, _P]),
 }
 
 _lib = None

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip", "mgn_host.cpp"]
+SOURCES = ["mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip", "mgn_halo.hip", "mgn_host.cpp"]
 OUT = os.path.join(PKG, "libmgn_hip.so")
 
 

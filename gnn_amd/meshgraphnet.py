@@ -147,7 +147,7 @@ class EdgeNodeMessagePassing(nn.Module):
         updated edge latents are not written (last block of a stack).  With a ``halo`` plan only
         the first ``halo.num_owned`` rows of ``x`` are owned; the sender projections of the
         remaining (halo) rows arrive from their owners.  ``packed``: this block's (edge, node) entries of an
-        ``ops.PackedWeights`` refreshed in this call (single-GPU path only)."""
+        ``ops.PackedWeights`` refreshed in this call."""
         ew, nw = self.edge_mlp.weights(), self.node_mlp.weights()
         n = x.shape[0] if halo is None else halo.num_owned
         e_out = e_csr if store_edges else None
@@ -162,32 +162,23 @@ class EdgeNodeMessagePassing(nn.Module):
                        torch.empty(e_csr.shape[0], dtype=torch.float32, device=x.device))
                 self.__dict__["_att"] = buf
             a_proj, alpha, wts = buf
-            ops.train_linear_fwd(x[:n], self.attn_lin.weight.data, 0, a_proj[:n], bias=self.attn_lin.bias.data)
+            ops.train_linear_fwd(x if halo is None else x[:n], self.attn_lin.weight.data, 0,
+                                 a_proj if halo is None else a_proj[:n], bias=self.attn_lin.bias.data)
             if halo is not None:
                 halo.exchange_rows(a_proj)
             ops.edge_attention(a_proj, topo.rowptr, topo.sender, topo.recv, alpha, wts)
-        if halo is None and not ops.timing_enabled():       # the common path, without the timing contexts
-            if not projected:
-                ops.mp_project(x, self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps, pr)
-            ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, edge_weight=wts,
-                        packed=packed[0] if packed is not None else None)
-            nxt = next_block.edge_mlp._modules["0"]._parameters if next_block is not None else None
-            if packed is not None:
-                if nxt is None:
-                    ops.mp_node_packed(x, aggr, topo.rowptr, nw, packed[1], x)
-                else:
-                    ops.mp_node_packed(x, aggr, topo.rowptr, nw, packed[1], x, nxt["weight"].data, nxt["bias"].data, ps, pr)
-            elif nxt is None:
-                ops.mp_node(x, aggr, topo.rowptr, nw, x)
-            else:
-                ops.mp_node_project(x, aggr, topo.rowptr, nw, nxt["weight"].data, nxt["bias"].data, x, ps, pr)
-            return
+        nxt = next_block.edge_mlp._modules["0"]._parameters if next_block is not None else None
+        if halo is None:
+            xo, ao, rp, pso, pro = x, aggr, topo.rowptr, ps, pr
+        else:                                     # the rows this rank owns
+            xo, ao, rp, pso, pro = x[:n], aggr[:n], topo.rowptr[: n + 1], ps[:n], pr[:n]
         if not projected:
             with ops.timed("mp_project"):
-                ops.mp_project(x[:n], self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, ps[:n], pr[:n])
+                ops.mp_project(xo, self.edge_mlp[0].weight.data, self.edge_mlp[0].bias.data, pso, pro)
+        pk_e = packed[0] if packed is not None else None
         if halo is None:
             with ops.timed("mp_edge"):
-                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, edge_weight=wts)
+                ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, edge_weight=wts, packed=pk_e)
         else:
             # the receivers whose in-edges all come from owned senders are updated while the halo
             # rows of `ps` are in flight; the rest follows once they have arrived
@@ -195,19 +186,23 @@ class EdgeNodeMessagePassing(nn.Module):
                 pending = halo.exchange_rows(ps, async_op=True)
             with ops.timed("mp_edge"):
                 ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=halo.interior,
-                            edge_weight=wts)
+                            edge_weight=wts, packed=pk_e)
             if pending is not None:
                 pending.wait()
             with ops.timed("mp_edge_boundary"):
                 for rng in halo.boundary:
                     ops.mp_edge(e_csr, ps, pr, topo.rowptr, topo.sender, topo.recv, ew, e_out, aggr, node_range=rng,
-                                edge_weight=wts)
+                                edge_weight=wts, packed=pk_e)
         with ops.timed("mp_node"):
-            if next_block is None:
-                ops.mp_node(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, x[:n])
+            if packed is not None:
+                if nxt is None:
+                    ops.mp_node_packed(xo, ao, rp, nw, packed[1], xo)
+                else:
+                    ops.mp_node_packed(xo, ao, rp, nw, packed[1], xo, nxt["weight"].data, nxt["bias"].data, pso, pro)
+            elif nxt is None:
+                ops.mp_node(xo, ao, rp, nw, xo)
             else:
-                ops.mp_node_project(x[:n], aggr[:n], topo.rowptr[: n + 1], nw, next_block.edge_mlp[0].weight.data,
-                                    next_block.edge_mlp[0].bias.data, x[:n], ps[:n], pr[:n])
+                ops.mp_node_project(xo, ao, rp, nw, nxt["weight"].data, nxt["bias"].data, xo, pso, pro)
 
     def forward(self, node_feat, edge_index, edge_feat):
         """node_feat [N,H], edge_index [2,E] (row 0 sender, row 1 receiver), edge_feat [E,H]
@@ -379,19 +374,20 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         if halo is not None:
             if mesh.shape[0] != n:
                 raise RuntimeError(f"partitioned run: mesh_pos must hold the {n} local rows [owned | halo]")
-            if world.shape[0] == n_own:            # state fed back from predict(): owned rows only
-                world = torch.cat([world, world.new_empty(n - n_own, 2)])
-                phi = torch.cat([phi, phi.new_empty(n - n_own, 1)])
-            world, phi = halo.exchange_state(world, phi)
+            if world.shape[0] < n_own or phi.shape[0] < n_own:
+                raise RuntimeError(f"partitioned run: world_pos / phi must hold at least the {n_own} owned rows")
+            world, phi = halo.exchange_state(world, phi)      # [owned | halo] buffers of the plan, halo rows refreshed
         mat = self._f32(graph["mat_param"]) if self.with_mat_params else None
         ops.node_features(world[:n_own], mesh[:n_own], phi[:n_own], self._f32(graph["swelling_phi"])[:n_own],
                           self._f32(graph["node_type"])[:n_own], mat, ws.node_feat[:n_own])
         ops.edge_features(world, mesh, phi, topo.sender, topo.recv, ws.edge_feat)
-        hook_n = halo.sum_hook("node") if halo is not None else None
-        hook_e = halo.sum_hook("edge") if halo is not None else None
-        ms_n = self.node_features_normalizer.stats_for(ws.node_feat[:n_own], True, hook_n)
+        if halo is None:
+            ms_n = self.node_features_normalizer.stats_for(ws.node_feat, True)
+            ms_e = self.edge_features_normalizer.stats_for(ws.edge_feat, True)
+        else:                                     # partial sums of both normalisers in one all-reduce
+            ms_n, ms_e = halo.feature_stats(self.node_features_normalizer, ws.node_feat[:n_own],
+                                            self.edge_features_normalizer, ws.edge_feat)
         ops.encode(ws.node_feat[:n_own], ms_n, self.node_encoder.weights(), ws.x[:n_own])
-        ms_e = self.edge_features_normalizer.stats_for(ws.edge_feat, True, hook_e)
         ops.encode(ws.edge_feat, ms_e, self.edge_encoder.weights(), ws.e)
         cg = cw = None
         if self.sample_ratio > 0:                 # core/meshgraphnet.py:179-182
@@ -405,8 +401,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             ops.gather_rows(ws.x, cg.first, cw.x)          # encoder output of the sampled nodes (:182)
         blocks = list(self.processors)
         # prepared weight sets (one conversion launch per call: a snapshot of the parameters, so never stale)
-        use_pk = (halo is None and not ops.timing_enabled() and ops.matmul_mode() == "f16x2"
-                  and os.environ.get("MGN_PACKED_WEIGHTS", "1") != "0")
+        use_pk = ops.matmul_mode() == "f16x2" and os.environ.get("MGN_PACKED_WEIGHTS", "1") != "0"
         pk = self._packed("_pk", blocks) if use_pk and blocks else None
         for i, proc in enumerate(blocks):
             last = i + 1 == len(blocks)           # nothing reads the edge latents after the last block

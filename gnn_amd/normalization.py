@@ -89,6 +89,40 @@ class Normalizer(nn.Module):
             return batched_data.reshape(n, f)
         return batched_data.permute(1, 0, 2).reshape(n, b * f)
 
+    def local_sums(self, rows2d: torch.Tensor, accumulate: bool = True, out: torch.Tensor = None):
+        """First half of :meth:`stats_for`: when accumulation is live, the float64 column sums
+        ``[sum | sum of squares]`` of ``rows2d`` [n, B*F] (into ``out`` [2*B*F] if given, else into the
+        instance's own buffer); returns that tensor, or None when nothing is to be accumulated."""
+        self._require_device()
+        if not (accumulate and self._num_accumulations < self._max_accumulations):
+            return None
+        w = self._work()
+        n, bf = rows2d.shape
+        need = ops.feature_sums_scratch_bytes(n, bf)
+        if w["scratch"] is None or w["scratch"].numel() * 8 < need:
+            w["scratch"] = torch.empty((need + 7) // 8, dtype=torch.float64, device=rows2d.device)
+        sums = w["sums"] if out is None else out
+        ops.feature_sums(rows2d, sums, w["scratch"])
+        return sums
+
+    def fold(self, sums, rows: int) -> torch.Tensor:
+        """Second half of :meth:`stats_for`: folds ``sums`` (from :meth:`local_sums`, possibly reduced over
+        ranks since; None = nothing to accumulate) over ``rows`` rows into the statistics
+        (core/normalization.py:30-37) and returns the device vector ``[mean | std]`` (:39-48)."""
+        self._require_device()
+        w = self._work()
+        added = 0
+        if sums is not None:
+            added = int(rows)
+            self._acc_count += added
+            self._num_accumulations += 1
+        if w.get("count_dev") is not None:
+            ops.norm_update_counted(self._acc_sum, self._acc_sum_squared, sums, w["count_dev"], added, self._std_epsilon,
+                                    w["mean_std"])
+        else:
+            ops.norm_update(self._acc_sum, self._acc_sum_squared, sums, self._acc_count, self._std_epsilon, w["mean_std"])
+        return w["mean_std"]
+
     def stats_for(self, rows2d: torch.Tensor, accumulate: bool = True, partial_sums_hook=None) -> torch.Tensor:
         """Updates the statistics from ``rows2d`` [n, B*F] when accumulation is live
         (core/normalization.py:21-23, :30-37) and returns the device vector
@@ -97,27 +131,13 @@ class Normalizer(nn.Module):
         ``partial_sums_hook(sums_f64)`` may reduce the float64 sums across ranks in place
         before they are folded into the statistics (mesh-partitioned runs); it must also
         return the global row count."""
-        self._require_device()
-        w = self._work()
-        sums, added = None, 0
-        if accumulate and self._num_accumulations < self._max_accumulations:
-            n, bf = rows2d.shape
-            need = ops.feature_sums_scratch_bytes(n, bf)
-            if w["scratch"] is None or w["scratch"].numel() * 8 < need:
-                w["scratch"] = torch.empty((need + 7) // 8, dtype=torch.float64, device=rows2d.device)
-            ops.feature_sums(rows2d, w["sums"], w["scratch"])
-            sums = w["sums"]
+        sums = self.local_sums(rows2d, accumulate)
+        n = 0
+        if sums is not None:
+            n = rows2d.shape[0]
             if partial_sums_hook is not None:
                 n = int(partial_sums_hook(sums))
-            self._acc_count += n
-            self._num_accumulations += 1
-            added = n
-        if w.get("count_dev") is not None:
-            ops.norm_update_counted(self._acc_sum, self._acc_sum_squared, sums, w["count_dev"], added, self._std_epsilon,
-                                    w["mean_std"])
-        else:
-            ops.norm_update(self._acc_sum, self._acc_sum_squared, sums, self._acc_count, self._std_epsilon, w["mean_std"])
-        return w["mean_std"]
+        return self.fold(sums, n)
 
     # ----------------------------------------------------------------- reference API
     def forward(self, batched_data, accumulate=True, partial_sums_hook=None):

@@ -507,6 +507,52 @@ def scatter_rows(src, idx, dst):
     _lib.check(rc, "mgn_scatter_rows")
 
 
+# --------------------------------------------------------------------------- device: halo exchange (partitioned meshes)
+def halo_pack(src, send_idx, send_buf):
+    """send_buf[i] = src[send_idx[i]] (rows of any width; ``send_idx`` int32, every entry a valid row of ``src``)."""
+    m, wd = send_buf.shape
+    rc = _lib.lib().mgn_halo_pack(_dev(src, torch.float32, (None, wd), "src"), _dev(send_idx, torch.int32, (m,), "send_idx"),
+                                  _dev(send_buf, torch.float32, (m, wd), "send_buf"), m, wd, _stream())
+    _lib.check(rc, "mgn_halo_pack")
+
+
+def halo_unpack_add(recv_buf, add_rowptr, add_rows, add_pos, buf):
+    """buf[add_rows[d]] += recv_buf[add_pos[k]] for k in add_rowptr[d] .. add_rowptr[d+1]-1, in that order."""
+    wd, nd = buf.shape[1], add_rows.shape[0]
+    rc = _lib.lib().mgn_halo_unpack_add(
+        _dev(recv_buf, torch.float32, (add_pos.shape[0], wd), "recv_buf"), _dev(add_rowptr, torch.int32, (nd + 1,), "add_rowptr"),
+        _dev(add_rows, torch.int32, (nd,), "add_rows"), _dev(add_pos, torch.int32, (None,), "add_pos"),
+        _dev(buf, torch.float32, (None, wd), "buf"), nd, wd, _stream())
+    _lib.check(rc, "mgn_halo_unpack_add")
+
+
+def halo_stage_state(world_pos, phi, n_owned, send_idx, world_local, phi_local, send_buf):
+    """Copies the owned rows of (world_pos, phi) into the local [owned | halo] arrays and writes the
+    3-float records (x, y, phi) of the rows listed in ``send_idx`` to ``send_buf``."""
+    m = send_idx.shape[0]
+    n_loc = world_local.shape[0]
+    if world_pos.shape[0] < n_owned or phi.shape[0] < n_owned or n_loc < n_owned:
+        raise RuntimeError("halo_stage_state: fewer rows than owned nodes")
+    rc = _lib.lib().mgn_halo_stage_state(
+        _dev(world_pos, torch.float32, (None, 2), "world_pos"), _dev(phi, torch.float32, (None, 1), "phi"), n_owned,
+        _dev(send_idx, torch.int32, (m,), "send_idx"), m, _dev(world_local, torch.float32, (n_loc, 2), "world_local"),
+        _dev(phi_local, torch.float32, (n_loc, 1), "phi_local"), _dev(send_buf, torch.float32, (m, 3), "send_buf"), _stream())
+    _lib.check(rc, "mgn_halo_stage_state")
+
+
+def halo_unpack_state(recv_buf, n_owned, world_local, phi_local):
+    """Writes the received 3-float records into the halo rows (from row ``n_owned``) of the local arrays."""
+    m, n_loc = recv_buf.shape[0], world_local.shape[0]
+    if n_owned + m != n_loc:
+        raise RuntimeError("halo_unpack_state: owned + received rows must fill the local arrays")
+    _dev(world_local, torch.float32, (n_loc, 2), "world_local")
+    _dev(phi_local, torch.float32, (n_loc, 1), "phi_local")
+    rc = _lib.lib().mgn_halo_unpack_state(_dev(recv_buf, torch.float32, (m, 3), "recv_buf"), m,
+                                          C.c_void_p(world_local.data_ptr() + 8 * n_owned),
+                                          C.c_void_p(phi_local.data_ptr() + 4 * n_owned), _stream())
+    _lib.check(rc, "mgn_halo_unpack_state")
+
+
 # --------------------------------------------------------------------------- device: training blocks
 _MODES = ("f32", "bf16x3", "f16x2")
 

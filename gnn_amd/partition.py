@@ -11,7 +11,8 @@ ascending, the halo block is already grouped by owner rank, so an
 Per message-passing step one exchange moves the 128-float sender projections of the
 halo nodes; per rollout step one exchange moves their (world_pos, phi); the normaliser
 sums are all-reduced while accumulation is live.  ``torch.distributed`` (RCCL on GPUs,
-gloo in the CPU tests) does the transport; packing uses ``index_select`` (a copy).
+gloo in the CPU tests) does the transport; the rows are packed and unpacked by the library's
+``mgn_halo_*`` kernels into buffers the plan owns, so an exchange allocates nothing.
 """
 from __future__ import annotations
 
@@ -21,6 +22,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import ops
 from .graph import MeshGraph, Topology
 
 
@@ -94,12 +96,40 @@ class HaloPlan:
     # ------------------------------------------------------------------ device side
     def to(self, device, group=None) -> "HaloPlan":
         """Builds the local receiver-major topology on ``device`` (needs libmgn_hip.so for its
-        host CSR routine) and uploads the send list."""
+        host CSR routine), uploads the send list and the add-back lists of the reverse exchange, and
+        creates the buffers the exchanges reuse from step to step (nothing is allocated per step)."""
         self.topology = Topology(torch.from_numpy(self.local_edge_index), self.num_local, device)
-        self.send_idx = torch.from_numpy(self.send_local_ids).to(device)
+        if self.send_local_ids.size and (self.send_local_ids.min() < 0 or self.send_local_ids.max() >= self.num_owned):
+            raise ValueError("HaloPlan: a send index lies outside the owned rows")
+        dev = self.topology.rowptr.device
+        self.device = dev
+        self.num_send = int(self.send_local_ids.shape[0])
+        self.send_idx = torch.from_numpy(self.send_local_ids.astype(np.int32)).to(dev)
+        # reverse exchange: positions of the returned rows grouped by the owned row they are added to, peers
+        # ascending within a row (the returned buffer is ordered like the send list, i.e. by peer)
+        order = np.argsort(self.send_local_ids, kind="stable")
+        rows, counts = np.unique(self.send_local_ids, return_counts=True)
+        rowptr = np.zeros(rows.shape[0] + 1, dtype=np.int32)
+        np.cumsum(counts, out=rowptr[1:])
+        self.add_rows = torch.from_numpy(rows.astype(np.int32)).to(dev)
+        self.add_rowptr = torch.from_numpy(rowptr).to(dev)
+        self.add_pos = torch.from_numpy(order.astype(np.int32)).to(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.world, self.phi = torch.empty(self.num_local, 2, **f32), torch.empty(self.num_local, 1, **f32)
+        self._state_send, self._state_recv = torch.empty(self.num_send, 3, **f32), torch.empty(self.num_halo, 3, **f32)
+        self._bufs = {}
+        self._in_flight = None
         self.group = group
         self._ranges(self.topology.rowptr.cpu().numpy())
         return self
+
+    def _buffer(self, kind: str, width: int) -> torch.Tensor:
+        """Persistent [num_send, width] buffer: ``kind`` "send" (rows packed for the peers) or "ret"
+        (rows the peers return in the reverse exchange)."""
+        buf = self._bufs.get((kind, width))
+        if buf is None:
+            buf = self._bufs[(kind, width)] = torch.empty(self.num_send, width, dtype=torch.float32, device=self.device)
+        return buf
 
     def _ranges(self, rowptr: np.ndarray) -> None:
         """Splits the owned receivers into the longest contiguous run whose in-edges all come from
@@ -111,12 +141,10 @@ class HaloPlan:
         ls, lr = self.local_edge_index[0], self.local_edge_index[1]
         needs_halo[lr[ls >= n_own]] = True
         needs_halo[n_own] = True                       # sentinel
-        best, start = (0, 0), 0
-        for stop in np.nonzero(needs_halo)[0]:         # maximal unflagged runs end at flagged nodes
-            if stop - start > best[1] - best[0]:
-                best = (start, int(stop))
-            start = int(stop) + 1
-        a, b = best
+        flagged = np.nonzero(needs_halo)[0]
+        starts = np.concatenate([[0], flagged[:-1] + 1])   # maximal unflagged runs end at flagged nodes
+        k = int(np.argmax(flagged - starts))               # first of the longest
+        a, b = int(starts[k]), int(flagged[k])
         cnt = lambda n0, n1: int(rowptr[n1]) - int(rowptr[n0])
         self.interior = (a, b, cnt(a, b))
         self.boundary = [r for r in ((0, a, cnt(0, a)), (b, n_own, cnt(b, n_own))) if r[1] > r[0]]
@@ -138,56 +166,27 @@ class HaloPlan:
                 out[k] = v
         return out
 
-    def exchange_rows(self, buf: torch.Tensor, async_op: bool = False):
-        """``buf`` is [num_local, W]; rows [0, num_owned) are valid.  Fills the halo rows with
-        the owners' values.  Returns ``buf``, or with ``async_op`` a handle whose ``wait()`` makes
-        the current stream wait for the halo rows (None when there is nothing to wait for)."""
-        if self.world_size == 1:
-            return None if async_op else buf
-        send = buf.index_select(0, self.send_idx) if self.send_idx.numel() else buf.new_empty((0, buf.shape[1]))
-        recv = buf[self.num_owned:]
-        if self._host_staged(buf):
-            return self._staged_all_to_all(recv, send, self.recv_counts, self.send_counts, async_op, buf)
-        work = dist.all_to_all_single(recv, send, output_split_sizes=self.recv_counts, input_split_sizes=self.send_counts,
+    # The three primitives below are the whole transport; everything else packs and unpacks with the library's
+    # kernels into buffers the plan owns.  (The in-process tests replace exactly these.)
+    def _all_to_all(self, recv, send, recv_counts, send_counts, async_op):
+        """Rows of ``send`` (grouped by peer, ``send_counts``) to the peers, theirs into ``recv`` (``recv_counts``).
+        Returns None once ``recv`` is ordered behind the exchange on the current stream, or with ``async_op`` a
+        handle whose ``wait()`` establishes that order."""
+        if self._host_staged(recv):
+            recv_c = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(recv_c, send.cpu(), output_split_sizes=recv_counts, input_split_sizes=send_counts,
+                                   group=self.group)
+
+            class _Staged:
+                def wait(self_inner):
+                    recv.copy_(recv_c)
+
+            if async_op:
+                return _Staged()
+            recv.copy_(recv_c)
+            return None
+        return dist.all_to_all_single(recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts,
                                       group=self.group, async_op=async_op)
-        return work if async_op else buf
-
-    def return_rows(self, buf: torch.Tensor, async_op: bool = False):
-        """The reverse of :meth:`exchange_rows`, for gradients: the halo rows of ``buf``
-        [num_local, W] travel to their owners, which add them to their own rows (peer by peer in
-        rank order, so the result does not depend on timing).  Returns ``buf``, or with
-        ``async_op`` a handle whose ``wait()`` completes the addition (None when there is nothing
-        to do)."""
-        if self.world_size == 1:
-            return None if async_op else buf
-        send = buf[self.num_owned:].contiguous()
-        recv = buf.new_empty((int(self.send_idx.numel()), buf.shape[1]))
-        if self._host_staged(buf):
-            work = self._staged_all_to_all(recv, send, self.send_counts, self.recv_counts, True, None)
-        else:
-            work = dist.all_to_all_single(recv, send, output_split_sizes=self.send_counts,
-                                          input_split_sizes=self.recv_counts, group=self.group, async_op=async_op)
-        plan = self
-
-        class _Pending:
-            def wait(self_inner):
-                if work is not None:
-                    work.wait()
-                plan._add_returned(buf, recv)
-
-        if async_op:
-            return _Pending()
-        _Pending().wait()                         # the host-staged transport hands back a handle in both modes
-        return buf
-
-    def _add_returned(self, buf: torch.Tensor, recv: torch.Tensor) -> None:
-        off = 0
-        for q in range(self.world_size):          # ids are unique within one peer's list
-            cnt = self.send_counts[q]
-            if cnt:
-                ids = self.send_idx[off: off + cnt]
-                buf[ids] += recv[off: off + cnt]
-                off += cnt
 
     def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
         """Sum over the ranks of the plan's group, in place."""
@@ -206,27 +205,110 @@ class HaloPlan:
     def _host_staged(self, t: torch.Tensor) -> bool:
         return t.is_cuda and dist.get_backend(self.group) == "gloo"
 
-    def _staged_all_to_all(self, recv, send, out_splits, in_splits, async_op, ret):
-        recv_c = torch.empty(recv.shape, dtype=recv.dtype)
-        dist.all_to_all_single(recv_c, send.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits,
-                               group=self.group)
+    def _settle(self):
+        """The send / return buffers are reused: an exchange still in flight is completed before the next one packs."""
+        pending, self._in_flight = self._in_flight, None
+        if pending is not None:
+            pending.wait()
 
-        class _Done:
+    def exchange_rows(self, buf: torch.Tensor, async_op: bool = False):
+        """``buf`` is [num_local, W]; rows [0, num_owned) are valid.  Fills the halo rows with
+        the owners' values.  Returns ``buf``, or with ``async_op`` a handle whose ``wait()`` makes
+        the current stream wait for the halo rows (None when there is nothing to wait for)."""
+        if self.world_size == 1:
+            return None if async_op else buf
+        self._settle()
+        if buf.is_cuda:
+            send = self._buffer("send", buf.shape[1])
+            ops.halo_pack(buf, self.send_idx, send)
+        else:                                     # CPU tensors (host-side tests of the plan): torch indexing
+            send = buf.index_select(0, self.send_idx.to(torch.int64))
+        work = self._all_to_all(buf[self.num_owned:], send, self.recv_counts, self.send_counts, async_op)
+        if not async_op:
+            return buf
+        if work is None:
+            return None
+        plan = self
+
+        class _Pending:
             def wait(self_inner):
-                recv.copy_(recv_c)
+                if plan._in_flight is self_inner:
+                    plan._in_flight = None
+                    work.wait()
 
+        self._in_flight = _Pending()
+        return self._in_flight
+
+    def return_rows(self, buf: torch.Tensor, async_op: bool = False):
+        """The reverse of :meth:`exchange_rows`, for gradients: the halo rows of ``buf``
+        [num_local, W] travel to their owners, which add them to their own rows (peer by peer in
+        rank order, so the result does not depend on timing).  Returns ``buf``, or with
+        ``async_op`` a handle whose ``wait()`` completes the addition (None when there is nothing
+        to do)."""
+        if self.world_size == 1:
+            return None if async_op else buf
+        self._settle()
+        recv = self._buffer("ret", buf.shape[1]) if buf.is_cuda else buf.new_empty((self.num_send, buf.shape[1]))
+        work = self._all_to_all(recv, buf[self.num_owned:], self.send_counts, self.recv_counts, async_op)
+        plan = self
+
+        class _Pending:
+            def wait(self_inner):
+                if plan._in_flight is not self_inner:
+                    return
+                plan._in_flight = None
+                if work is not None:
+                    work.wait()
+                plan._add_returned(buf, recv)
+
+        self._in_flight = _Pending()
         if async_op:
-            return _Done()
-        recv.copy_(recv_c)
-        return ret
+            return self._in_flight
+        self._in_flight.wait()
+        return buf
+
+    def _add_returned(self, buf: torch.Tensor, recv: torch.Tensor) -> None:
+        if buf.is_cuda:
+            ops.halo_unpack_add(recv, self.add_rowptr, self.add_rows, self.add_pos, buf)
+            return
+        off = 0
+        for q in range(self.world_size):          # ids are unique within one peer's list
+            cnt = self.send_counts[q]
+            if cnt:
+                ids = self.send_idx[off: off + cnt].to(torch.int64)
+                buf[ids] += recv[off: off + cnt]
+                off += cnt
 
     def exchange_state(self, world_pos: torch.Tensor, phi: torch.Tensor):
-        """Refreshes the halo rows of the per-step state (3 floats per halo node)."""
+        """The per-step state as local [owned | halo] arrays with the halo rows refreshed from their owners
+        (3 floats per halo node).  ``world_pos`` / ``phi`` hold at least the owned rows; the returned tensors
+        are buffers of the plan, overwritten by the next call."""
         if self.world_size == 1:
             return world_pos, phi
-        st = torch.cat([world_pos, phi], dim=1).contiguous()
-        self.exchange_rows(st)
-        return st[:, :2].contiguous(), st[:, 2:].contiguous()
+        if not world_pos.is_cuda:
+            st = torch.cat([world_pos, phi], dim=1)
+            if st.shape[0] == self.num_owned:
+                st = torch.cat([st, st.new_empty(self.num_halo, 3)])
+            self.exchange_rows(st)
+            return st[:, :2].contiguous(), st[:, 2:].contiguous()
+        self._settle()
+        ops.halo_stage_state(world_pos, phi, self.num_owned, self.send_idx, self.world, self.phi, self._state_send)
+        self._all_to_all(self._state_recv, self._state_send, self.recv_counts, self.send_counts, False)
+        ops.halo_unpack_state(self._state_recv, self.num_owned, self.world, self.phi)
+        return self.world, self.phi
+
+    def feature_stats(self, node_norm, node_rows, edge_norm, edge_rows):
+        """``[mean | std]`` of the node- and the edge-feature normaliser for this step (both accumulate first while
+        their accumulation is live): the float64 partial sums of both go through ONE all-reduce."""
+        fn, fe = node_rows.shape[1], edge_rows.shape[1]
+        buf = self._bufs.get(("sums", fn, fe))
+        if buf is None:
+            buf = self._bufs[("sums", fn, fe)] = torch.zeros(2 * (fn + fe), dtype=torch.float64, device=node_rows.device)
+        sn = node_norm.local_sums(node_rows, True, out=buf[: 2 * fn])
+        se = edge_norm.local_sums(edge_rows, True, out=buf[2 * fn:])
+        if sn is not None or se is not None:
+            self.all_reduce_(buf)
+        return node_norm.fold(sn, self.global_nodes), edge_norm.fold(se, self.global_edges)
 
     def sum_hook(self, kind: str):
         """Hook for ``Normalizer.stats_for``: all-reduces the float64 partial sums and returns

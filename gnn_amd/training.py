@@ -87,17 +87,17 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
     if halo is not None:
         if mesh.shape[0] != n_loc:
             raise RuntimeError(f"partitioned run: mesh_pos must hold the {n_loc} local rows [owned | halo]")
-        if world.shape[0] == n:                    # owned rows only: make room for the halo rows
-            world = torch.cat([world, world.new_empty(n_loc - n, 2)])
-            phi = torch.cat([phi, phi.new_empty(n_loc - n, 1)])
-        world, phi = halo.exchange_state(world, phi)
+        world, phi = halo.exchange_state(world, phi)      # [owned | halo] buffers of the plan, halo rows refreshed
     mat = f32(graph["mat_param"]) if model.with_mat_params else None
     nfeat = torch.empty(n, node_f, dtype=torch.float32, device=dev)
     efeat = torch.empty(e, 7, dtype=torch.float32, device=dev)
     ops.node_features(world[:n], mesh[:n], phi[:n], f32(graph["swelling_phi"])[:n], node_type, mat, nfeat)
     ops.edge_features(world, mesh, phi, topo.sender, topo.recv, efeat)
-    ms_n = model.node_features_normalizer.stats_for(nfeat, True, halo.sum_hook("node") if halo is not None else None)
-    ms_e = model.edge_features_normalizer.stats_for(efeat, True, halo.sum_hook("edge") if halo is not None else None)
+    if halo is None:
+        ms_n = model.node_features_normalizer.stats_for(nfeat, True)
+        ms_e = model.edge_features_normalizer.stats_for(efeat, True)
+    else:                                          # partial sums of both normalisers in one all-reduce
+        ms_n, ms_e = halo.feature_stats(model.node_features_normalizer, nfeat, model.edge_features_normalizer, efeat)
     nf_pad, ef_pad = _empty(n, dev), _empty(e, dev)
     ops.train_pad_features(nfeat, ms_n, nf_pad)
     ops.train_pad_features(efeat, ms_e, ef_pad)

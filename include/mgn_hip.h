@@ -404,6 +404,34 @@ int mgn_adam_step(const void* table_dev, int32_t n_entries, float lr, float beta
 int mgn_adam_hyper(float lr, float beta1, float beta2, float eps, float weight_decay, int64_t step, float* hyper6 /*host*/);
 int mgn_adam_step_dev(const void* table_dev, int32_t n_entries, const float* hyper_dev, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * One-hop halo exchange of a mesh partitioned by contiguous node ranges.  The reference runs one mesh on one device
+ * (core/rollout.py:28, run_train_multiscale.py:97-98, :138); split over several GPUs, the edge update of
+ * core/meshgraphnet.py:95 needs the latents of senders owned by another rank.  A rank numbers its rows
+ * [owned | halo], the halo grouped by owner; the transport between ranks (RCCL send/recv or all-to-all, issued by the
+ * caller) moves contiguous buffers and receives the forward halo straight into rows num_owned.. of the tensor.
+ * These entry points move rows between the row-indexed tensors and those buffers; none allocates, none uses atomics.
+ *
+ * mgn_halo_pack: send_buf[i][:] = src[send_idx[i]][:] -- the owned rows the peers need, grouped by peer (per block:
+ *   the sender projections `ps`; with the attention option also the attn_lin rows).  Any width > 0.
+ * mgn_halo_unpack_add: the reverse exchange of the backward pass (gradients of halo rows return to their owners):
+ *   buf[add_rows[d]][:] += recv_buf[add_pos[k]][:] for k in [add_rowptr[d], add_rowptr[d+1]) in that order, where
+ *   recv_buf holds the returned rows in the order of send_idx and the lists group its positions by destination row,
+ *   peers ascending: a fixed summation order.  width % 4 == 0.
+ * mgn_halo_stage_state / mgn_halo_unpack_state: the per-rollout-step exchange of the state that the edge features
+ *   read at both end points (core/meshgraphnet.py:226-235; fed back per step at core/rollout.py:29-32): copies the
+ *   owned rows of (world_pos [.,2], phi [.,1]) into the local [owned | halo] arrays (skipped when they alias) and
+ *   writes the records (x, y, phi) of the rows in send_idx to send_buf [n_send][3]; after the exchange the received
+ *   records [n_halo][3] are written to world_halo = world_local + 2 * num_owned, phi_halo = phi_local + num_owned.
+ * Every send_idx / add_rows entry must be a valid owned row: the plan that produced them guarantees it, the kernels
+ * do not check. */
+int mgn_halo_pack(const float* src, const int32_t* send_idx, float* send_buf, int64_t n_send, int32_t width, void* stream);
+int mgn_halo_unpack_add(const float* recv_buf, const int32_t* add_rowptr, const int32_t* add_rows, const int32_t* add_pos,
+                        float* buf, int64_t n_rows, int32_t width, void* stream);
+int mgn_halo_stage_state(const float* world_pos, const float* phi, int64_t n_owned, const int32_t* send_idx, int64_t n_send,
+                         float* world_local, float* phi_local, float* send_buf, void* stream);
+int mgn_halo_unpack_state(const float* recv_buf, int64_t n_halo, float* world_halo, float* phi_halo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
