@@ -44,27 +44,28 @@ FLOP_PER_EDGE_EDGE_KERNEL = 2 * (128 * 128 + 128 * 128)    # 65536: what mp_edge
 BYTES_PER_EDGE_EDGE_KERNEL = 512 + 512 + 8                 # e in, e out, sender + receiver ids
 
 
-def pmc_traffic(kernel, edges, file="r02_pmc_traffic.json"):
-    """HBM bytes per launch of `kernel` from the committed counter pass (FETCH_SIZE and WRITE_SIZE are
-    collected in separate rocprofv3 --pmc runs, which a timed run cannot do itself); scales with the
-    edge count, None when no pass for this kernel is on file."""
-    path = os.path.join(ROOT, "profiles", file)
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except OSError:
-        return None
+def pmc_record(files=("r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+    """The newest committed counter record among `files` (profiles/): FETCH_SIZE and WRITE_SIZE are collected in
+    separate rocprofv3 --pmc runs, which a timed run cannot do itself."""
+    for name in files:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                rec = json.load(f)
+            rec["file"] = "profiles/" + name
+            return rec
+        except OSError:
+            continue
+    return {}
+
+
+def pmc_traffic(kernel, units, files=("r03_pmc_traffic.json", "r02_pmc_traffic.json")):
+    """HBM bytes per launch of `kernel` from the committed counter pass, scaled to `units` edges (or nodes, for a
+    record taken per node); None when no pass for this kernel is on file."""
+    rec = pmc_record(files)
     if rec.get("kernel") != kernel:
         return None
-    return rec["traffic_bytes_per_edge"] * edges
-
-
-def pmc_record():
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            return json.load(f)
-    except OSError:
-        return {}
+    per = rec.get("traffic_bytes_per_edge", rec.get("traffic_bytes_per_node"))
+    return None if per is None else per * units
 
 
 def parse():
@@ -79,6 +80,7 @@ def parse():
                     help="N > 1: partition the fixed grid x grid mesh (strong) or keep grid x grid nodes per GPU (weak)")
     ap.add_argument("--reorder", choices=("none", "morton", "rcm"), default="none",
                     help="N = 1 experiment: renumber the mesh nodes before the run (the headline workload is row-major: none)")
+    ap.add_argument("--strict-steps", type=int, default=2, help="N = 1: timed steps of the strict fp32 matrix path (0 = skip)")
     ap.add_argument("--train-steps", type=int, default=3, help="N = 1: timed training steps for the `train` object (0 = skip)")
     ap.add_argument("--train-grid", type=int, default=500)
     ap.add_argument("--train-mp-steps", type=int, default=10)
@@ -182,8 +184,8 @@ def train_object(args, device):
         bytes_alg = (3 * 512 + 8) * e
         out["roofline"] = {"kernel": "train_edge_bwd_kernel", "bound": "hbm", "achieved": bytes_alg / t / 1e9,
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": bytes_alg / t / 1e9 / PEAK_HBM_GBS,
-                           "traffic": pmc_traffic("train_edge_bwd_kernel", e, "r02_pmc_traffic_train.json"),
-                           "traffic_unit": "bytes per launch (rocprofv3 PMC passes, profiles/r02_pmc_traffic_train.json)",
+                           "traffic": pmc_traffic("train_edge_bwd_kernel", e, ("r03_pmc_traffic_train.json", "r02_pmc_traffic_train.json")),
+                           "traffic_unit": "bytes per launch (rocprofv3 PMC passes, profiles/r0*_pmc_traffic_train.json)",
                            "avg_launch_ms": t * 1e3, "bytes_per_edge_algorithmic": 3 * 512 + 8}
     return out
 
@@ -265,6 +267,23 @@ def other_configs(device, cpu=True):
     torch.cuda.synchronize(device); dt = (time.perf_counter() - t0) / 4
     out["batched_100k_x8"] = {"workload": "317x317-node mesh, 15 MP steps, 8 trajectories as one block-diagonal graph",
                               "ms_per_step": dt * 1e3, "trajectory_steps_per_s": 8 / dt, "edge_updates_per_s": e * 15 / dt}
+    if cpu:
+        # one trajectory of the same mesh on the host cores: the CPU oracle's predict (1 warm-up + 1 timed call)
+        import oracle as O
+        cfg = O.OracleConfig(process_steps=15)
+        sd, norms = O.init_state_dict(cfg, 0), O.make_norms(cfg)
+        f1 = gnn_amd.synthetic_frames(316, 316, seed=0)[0]
+        fr = {k: f1[k] for k in ("world_pos", "mesh_pos", "phi", "swelling_phi", "node_type", "mat_param", "edge_index")}
+        with torch.no_grad():
+            O.predict(sd, cfg, norms, fr)
+            t0 = time.perf_counter()
+            O.predict(sd, cfg, norms, fr)
+            dtc = time.perf_counter() - t0
+        e1 = f1["edge_index"].shape[1]
+        out["batched_100k_x8"]["cpu_baseline"] = {
+            "value": 1.0 / dtc, "unit": "trajectory steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 timed + 1 warm-up predict call of the CPU oracle on ONE 317x317-node trajectory (15 MP steps)",
+            "ms_per_step": dtc * 1e3, "edge_updates_per_s": e1 * 15 / dtc}
     return out
 
 
@@ -329,30 +348,64 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(k):
+        """Wall time of k steps between two barrier + synchronize points, maximum over the ranks."""
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step(g)
+        sync()
+        t = time.perf_counter() - t0
+        if world_size > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([t], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t = float(tt.item())
+        return t
+
+    def kernel_times(log):
+        per = {}
+        for name, s0, s1 in log:
+            per.setdefault(name, []).append(s0.elapsed_time(s1))
+        return per
+
     for _ in range(args.warmup):
         step(g)
+    # the K timed steps: the launch sequence users get, nothing recorded in between
+    dt = timed_steps(args.steps)
+    # the same K steps again with HIP events around every launch (on the launch stream) for the per-kernel times;
+    # the launch sequence is identical, the events add host work and small gaps, so this is not the headline time
     log = []
     ops.set_event_log(log)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(g)
-    sync()
-    dt = time.perf_counter() - t0
+    dt_inst = timed_steps(args.steps)
     ops.set_event_log(None)
-    if world_size > 1:
-        import torch.distributed as dist
-        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    mode = ops.matmul_mode()
     ops.raise_if_out_of_range("bench.py")
     finite = bool(torch.isfinite(g["world_pos"]).all())
-
-    # per-kernel device time from the events recorded inside the timed region
-    per = {}
-    for name, s, t in log:
-        per.setdefault(name, []).append(s.elapsed_time(t))
+    per = kernel_times(log)
     kern_ms = {k: float(np.mean(v)) for k, v in per.items()}
+
+    strict = None
+    if world_size == 1 and mode != "f32" and args.strict_steps > 0:
+        # the same workload on the strict path: fp32 matrix instructions everywhere, no operand splitting
+        ops.set_matmul_mode("f32")
+        try:
+            step(g)
+            dts = timed_steps(args.strict_steps)
+            slog = []
+            ops.set_event_log(slog)
+            step(g)
+            torch.cuda.synchronize()
+            ops.set_event_log(None)
+            sper = kernel_times(slog)
+            strict = {"matrix_path": "v_mfma_f32_32x32x2_f32 (MGN_MATMUL=f32)", "steps": args.strict_steps,
+                      "ms_per_step": dts / args.strict_steps * 1e3,
+                      "edge_updates_per_s": e * args.mp_steps * args.strict_steps / dts,
+                      "rollout_steps_per_s": args.strict_steps / dts,
+                      "edge_kernel_ms": float(np.mean(sper.get("mp_edge", [float("nan")]))),
+                      "node_kernel_ms": float(np.mean(sper.get("mp_node", [float("nan")])))}
+        finally:
+            ops.set_matmul_mode(mode)
 
     if rank == 0:
         e_local = plan.topology.num_edges if plan is not None else e
@@ -365,7 +418,8 @@ def main():
             "unit": "edge-updates/s",
             "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_step, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32 (2-term fp16 split operands, fp32 accumulate)" if os.environ.get("MGN_MATMUL", "f16x2") == "f16x2" else "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": {"f16x2": "f32 (2-term fp16 split operands, fp32 accumulate)", "bf16x3": "f32 (3-term bf16 split operands, fp32 accumulate)",
+                                                 "f32": "f32"}[mode], "data": "synthetic",
             "config": {"workload": f"synthetic {args.grid}x{rows}-node triangle mesh, one rollout step (predict) "
                                    f"= {args.mp_steps} MP steps + encoder + decoder + integrator",
                        "nodes": n, "edges": e, "mp_steps": args.mp_steps, "latent": 128, "node_order": "row-major" if args.reorder == "none" else args.reorder,
@@ -374,12 +428,15 @@ def main():
             "edge_updates_per_s_per_gpu": e * args.mp_steps * args.steps / dt / world_size,
             "rollout_steps_per_s": args.steps / dt,
             "finite": finite,
+            "matmul_mode": mode,
+            "ms_per_step_instrumented": dt_inst / args.steps * 1e3,
             "kernel_ms": kern_ms,
         }
+        if strict is not None:
+            out["strict_f32"] = strict
         if "mp_edge" in kern_ms:
             t_edge = kern_ms["mp_edge"] * 1e-3
             ach = FLOP_PER_EDGE_EDGE_KERNEL * e_kernel / t_edge / 1e12
-            mode = os.environ.get("MGN_MATMUL", "f16x2")
             kernel, path, pipe_peak, products = {
                 "f32": ("mp_edge_kernel", "v_mfma_f32_32x32x2_f32", PEAK_F32_MFMA_TFLOPS, 1),
                 "bf16x3": ("mp_edge3_kernel", "fp32 operands split exactly into 3 bf16 terms, 6 partial products on "
@@ -424,7 +481,9 @@ def main():
                 t_node = kern_ms["mp_node"] * 1e-3
                 out["roofline_node_kernel"] = {"kernel": "mp_node_h_kernel", "bound": "hbm", "achieved": per_node * n_local / t_node / 1e9,
                                                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": per_node * n_local / t_node / 1e9 / PEAK_HBM_GBS,
-                                               "traffic": None, "avg_launch_ms": kern_ms["mp_node"], "bytes_per_node_algorithmic": per_node}
+                                               "traffic": pmc_traffic("mp_node_h_kernel", n_local, ("r03_pmc_traffic_node.json",)),
+                                               "traffic_unit": "bytes per launch that writes projections (rocprofv3 PMC passes, profiles/r03_pmc_traffic_node.json)",
+                                               "avg_launch_ms": kern_ms["mp_node"], "bytes_per_node_algorithmic": per_node}
             # one MP step = everything the processor launches for one layer; the projection of
             # layers > 0 is fused into the previous layer's node kernel, so divide totals by layers
             n_layers = args.steps * args.mp_steps

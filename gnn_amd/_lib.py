@@ -34,6 +34,7 @@ SIGNATURES = {
     "mgn_get_matmul_mode": (C.c_int, []),
     "mgn_set_matmul_mode": (C.c_int, [C.c_int]),
     "mgn_range_check": (C.c_int, [_P, _I32, _P]),
+    "mgn_range_poll": (C.c_int, [_P, _P]),
     "mgn_cells_to_edge_index": (C.c_int, [_P, _I64, _P, _P, _I64, _P, _P]),
     "mgn_receiver_csr": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P]),
     "mgn_edge_build_workspace_bytes": (C.c_int64, [_I64]),
@@ -56,6 +57,7 @@ SIGNATURES = {
     "mgn_feature_sums_scratch_bytes": (_I64, [_I64, _I32]),
     "mgn_feature_sums": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "mgn_feature_sums_static": (C.c_int, [_P, _I64, _I32, _P, _P]),
+    "mgn_feature_sums_static_prepare": (C.c_int, []),
     "mgn_norm_update": (C.c_int, [_P, _P, _P, _I32, _I64, _F, _P, _P]),
     "mgn_norm_update_counted": (C.c_int, [_P, _P, _P, _I32, _P, _I64, _F, _P, _P]),
     "mgn_normalize": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P]),

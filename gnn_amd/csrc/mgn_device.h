@@ -521,6 +521,13 @@ inline int read_range_flag(int* tripped, int reset, hipStream_t stream, const ch
     return 0;
 }
 
+// enqueues a copy of this translation unit's range flag to `host_word` (pinned host memory) on `stream`; no synchronisation
+inline int poll_range_flag(int* host_word, hipStream_t stream, const char* name) {
+    const hipError_t e = hipMemcpyFromSymbolAsync(host_word, HIP_SYMBOL(g_range_flag), sizeof(unsigned), 0, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) { mgn_set_error("%s: %s", name, hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
+
 inline int check_launch(const char* what) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { mgn_set_error("%s: %s", what, hipGetErrorString(e)); return (int)e; }

@@ -11,3 +11,4 @@ void mgn_set_matmul_mode_internal(int mode);
 
 // range flag of the training translation unit (see mgn_range_check)
 int mgn_train_read_range_flag(int* tripped, int reset, void* stream);
+int mgn_train_poll_range_flag(int* host_word, void* stream);

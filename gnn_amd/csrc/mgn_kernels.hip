@@ -1600,6 +1600,11 @@ static int scratch_of_current_device(double** out, const char* name) {
     return 0;
 }
 
+extern "C" int mgn_feature_sums_static_prepare(void) {
+    double* part = nullptr;
+    return scratch_of_current_device(&part, "mgn_feature_sums_static_prepare");
+}
+
 extern "C" int mgn_feature_sums_static(const float* feat, int64_t rows, int32_t n_feat, double* sums, void* stream) {
     MGN_REQUIRE(rows >= 0 && n_feat > 0 && n_feat <= MGN_MAX_FEAT && sums, "mgn_feature_sums_static");
     if (rows > MGN_FEATURE_SUMS_STATIC_MAX_ROWS) {
@@ -1628,6 +1633,13 @@ extern "C" int mgn_range_check(int32_t* tripped, int32_t reset, void* stream) {
     int rc = read_range_flag(&t, reset, (hipStream_t)stream, "mgn_range_check");
     if (rc == 0) rc = mgn_train_read_range_flag(&t, reset, stream);
     if (rc == 0) *tripped = t;
+    return rc;
+}
+
+extern "C" int mgn_range_poll(int32_t* host_words, void* stream) {
+    MGN_REQUIRE(host_words, "mgn_range_poll");
+    int rc = poll_range_flag(host_words, (hipStream_t)stream, "mgn_range_poll");
+    if (rc == 0) rc = mgn_train_poll_range_flag(host_words + 1, stream);
     return rc;
 }
 

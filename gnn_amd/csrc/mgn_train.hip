@@ -1040,6 +1040,10 @@ int mgn_train_read_range_flag(int* tripped, int reset, void* stream) {
     return read_range_flag(tripped, reset, (hipStream_t)stream, "mgn_range_check");
 }
 
+int mgn_train_poll_range_flag(int* host_word, void* stream) {
+    return poll_range_flag(host_word, (hipStream_t)stream, "mgn_range_poll");
+}
+
 extern "C" int64_t mgn_train_scratch_bytes(void) {
     return (int64_t)TRAIN_BLOCKS_MAX * PARTIAL * (int64_t)sizeof(float);
 }

@@ -7,7 +7,7 @@ Public surface and checkpoint layout follow ``core/meshgraphnet.py`` of the refe
 ``state_dict`` has the reference's 136 keys and a seeded construction draws the same
 weights.  All arithmetic runs in libmgn_hip.so; there is no PyTorch or CPU fallback.  The attention option
 (:60-61, :100-108) and the coarse multiscale branch (:148-156, :179-194, :237-283), off in every shipped config,
-run in ``forward`` / ``predict`` / ``rollout``; ``loss`` covers the shipped configuration only and raises for them.
+run in ``forward`` / ``predict`` / ``rollout`` and in ``loss`` + backward.
 """
 from __future__ import annotations
 
@@ -422,14 +422,16 @@ class EncodeProcessDecodeMultiScale(nn.Module):
 
     # ----------------------------------------------------------------- reference API
     @_on_graph_device
-    def forward(self, batch):
-        """Normalised per-step deltas [time_dim, N, node_out_dim] (core/meshgraphnet.py:168-211)."""
+    def forward(self, batch, check_range: bool = True):
+        """Normalised per-step deltas [time_dim, N, node_out_dim] (core/meshgraphnet.py:168-211).
+        ``check_range`` as in :meth:`predict` (never checked while the stream is being captured into a HIP graph)."""
         ws, topo = self._encode_process(batch)
         halo = self.__dict__.get("halo")
         n = halo.num_owned if halo is not None else topo.num_nodes
         delta = torch.empty(self.time_dim, n, self.node_out_dim, dtype=torch.float32, device=ws.x.device)
         self._decode(ws, n, delta_norm=delta)
-        ops.raise_if_out_of_range("forward")
+        if check_range and not torch.cuda.is_current_stream_capturing():
+            ops.raise_if_out_of_range("forward")
         return delta
 
     @_on_graph_device
@@ -439,7 +441,8 @@ class EncodeProcessDecodeMultiScale(nn.Module):
 
         ``check_range``: read the range flag of the default matrix path after the launches (one small
         device-to-host copy, which waits for the step) and raise if an operand left the fp16 range; loops
-        that check once at their end (``rollout``) pass False."""
+        that check once at their end (``rollout``) pass False.  The flag is sticky: a check that comes later
+        loses nothing.  Never checked while the stream is being captured into a HIP graph."""
         if self.node_out_dim != 3:
             raise RuntimeError("predict: node_out_dim must be 3 (world_pos x, y and phi)")
         with torch.no_grad():
@@ -450,7 +453,7 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             pred = torch.empty(self.time_dim, n, 3, dtype=torch.float32, device=ws.x.device)
             self._decode(ws, n, out_mean_std=ms_o, world_pos=self._f32(graph["world_pos"])[:n],
                          phi=self._f32(graph["phi"])[:n], node_type=self._f32(graph["node_type"])[:n], pred=pred)
-        if check_range:
+        if check_range and not torch.cuda.is_current_stream_capturing():
             ops.raise_if_out_of_range("predict")
         return pred
 
@@ -482,14 +485,20 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         (core/meshgraphnet.py:285-304): returns (total, ux, uy, phi).  The output normaliser
         accumulates first (:290).  With gradients enabled the result carries the backward pass
         of the HIP training kernels, so ``loss.backward()`` fills ``.grad`` of every parameter
-        as run_train_multiscale.py:139-141 expects.  ``check_range`` as in :meth:`predict`."""
+        as run_train_multiscale.py:139-141 expects.  ``check_range``: as in :meth:`predict` for a call without
+        gradients; a training call does not wait for the GPU -- it polls the (sticky) flag without blocking, so an
+        operand beyond the range, in this forward pass or the backward pass that follows, raises at the next call
+        (``ops.raise_if_out_of_range`` after the loop catches the last step)."""
         from . import training
         tgt = self._normalized_target(graph)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()[1]):
+        training_call = torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list()[1])
+        if training_call:
             comps = training.loss_components(self, graph, tgt)
         else:
             comps, _ = training.forward_saving(self, graph, tgt)
-        if check_range:
+        if check_range and training_call:
+            ops.poll_out_of_range("loss")
+        elif check_range and not torch.cuda.is_current_stream_capturing():
             ops.raise_if_out_of_range("loss")
         return comps[0] + comps[1] + comps[2], comps[0], comps[1], comps[2]
 

@@ -405,6 +405,12 @@ def feature_sums(feat, sums, scratch):
     _lib.check(rc, "mgn_feature_sums")
 
 
+def feature_sums_static_prepare():
+    """Resolves, for the current device, the address of the buffer :func:`feature_sums_static` uses (needed once per
+    device before that function is called under HIP graph capture)."""
+    _lib.check(_lib.lib().mgn_feature_sums_static_prepare(), "mgn_feature_sums_static_prepare")
+
+
 def feature_sums_static(feat, sums):
     """:func:`feature_sums` through the entry point that allocates nothing and takes no workspace (the
     partial sums live in a buffer inside the library, one per GPU; calls overlapping on one GPU race)."""
@@ -589,6 +595,40 @@ def raise_if_out_of_range(what: str):
             "into two fp16 terms: |value| must stay below 65520, weights below 512); the results of this call are "
             "invalid.  Rerun with the environment variable MGN_MATMUL=bf16x3 (or gnn_amd.ops.set_matmul_mode('bf16x3')), "
             "which has no range limit.")
+
+
+class _RangePoll:
+    """Per-device state of the non-blocking range check: a pinned two-word landing buffer and the event that
+    marks the copy into it."""
+    by_dev = {}
+
+    def __init__(self):
+        self.words = torch.zeros(2, dtype=torch.int32).pin_memory()
+        self.event = torch.cuda.Event()
+        self.pending = False
+
+
+def poll_out_of_range(what: str):
+    """Non-blocking form of :func:`raise_if_out_of_range` for loops that must not stall the host (a training loop):
+    looks at the answer of the previous poll if the GPU has delivered it -- raising as
+    :func:`raise_if_out_of_range` does when the flag was up -- and enqueues the next poll behind the work issued so
+    far.  The flag is sticky, so an overflow is reported one call late at worst; finish a loop with
+    :func:`raise_if_out_of_range`.  Does nothing while the current stream is being captured."""
+    if matmul_mode() != "f16x2" or torch.cuda.is_current_stream_capturing():
+        return
+    dev = torch.cuda.current_device()
+    st = _RangePoll.by_dev.get(dev)
+    if st is None:
+        st = _RangePoll.by_dev[dev] = _RangePoll()
+    if st.pending:
+        if not st.event.query():
+            return                              # previous answer still on its way: ask again next time
+        st.pending = False
+        if int(st.words[0]) or int(st.words[1]):
+            raise_if_out_of_range(what)         # reads and clears the flag, raises
+    _lib.check(_lib.lib().mgn_range_poll(st.words.data_ptr(), _stream()), "mgn_range_poll")
+    st.event.record()
+    st.pending = True
 
 
 def train_scratch_bytes() -> int:

@@ -453,11 +453,19 @@ class CapturedTrainStep:
         return [nr._num_accumulations < nr._max_accumulations for nr in self.norms]
 
     def _same_mesh(self, frame):
+        """The frame's topology and mesh coordinates are those the captured step was built on: the very tensors
+        seen before (same object, not modified since: the step keeps them alive, so an address cannot be reused by
+        another mesh), or tensors of equal contents (compared on the device)."""
         st = self.static
-        return (st is not None and frame["edge_index"].shape == st["edge_index"].shape
-                and frame["mesh_pos"].shape == st["mesh_pos"].shape
-                and (frame["edge_index"].data_ptr() == self.mesh_key[0] or torch.equal(frame["edge_index"].to(st["edge_index"].device), st["edge_index"]))
-                and (frame["mesh_pos"].data_ptr() == self.mesh_key[1] or torch.equal(frame["mesh_pos"].to(st["mesh_pos"].device), st["mesh_pos"])))
+        if st is None:
+            return False
+        for k, (seen, version) in zip(("edge_index", "mesh_pos"), self.mesh_key):
+            t = frame[k]
+            if t is seen and t._version == version:
+                continue
+            if t.shape != st[k].shape or not torch.equal(t.to(st[k].device, st[k].dtype), st[k]):
+                return False
+        return True
 
     def _make_static(self, frame):
         """Private device copies of the frame: the input buffers of the captured step.  The first (eager) step already
@@ -468,7 +476,8 @@ class CapturedTrainStep:
         for k in self.FIELDS:
             if k in self.static:
                 self.static[k] = self.static[k].to(torch.float32).clone()
-        self.mesh_key = (frame["edge_index"].data_ptr(), frame["mesh_pos"].data_ptr())
+        # the caller's tensors themselves (kept alive) with their version counters
+        self.mesh_key = tuple((frame[k], frame[k]._version) for k in ("edge_index", "mesh_pos"))
 
     def _load(self, frame):
         for k in self.FIELDS:
@@ -502,7 +511,10 @@ class CapturedTrainStep:
     def close(self):
         for nr in self.norms:
             nr.use_device_count(False)
+        had_graph = self.graph is not None
         self.graph = self.static = self.out = None
+        if had_graph:
+            ops.raise_if_out_of_range("CapturedTrainStep")
 
     def __call__(self, frame):
         from . import ops
@@ -524,5 +536,5 @@ class CapturedTrainStep:
                 if acc:
                     nr.count_replayed(rows)
             out = self._replay()
-        ops.raise_if_out_of_range("CapturedTrainStep")
+        ops.poll_out_of_range("CapturedTrainStep")     # non-blocking; the flag is sticky, close() reads it once more
         return out

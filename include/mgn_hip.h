@@ -74,6 +74,12 @@ int mgn_set_matmul_mode(int mode);
  * weights after their pre-scale of 128), else 0; reset != 0 clears the flag.  Synchronises `stream`.  Callers
  * check once per forward pass or rollout and switch to MGN_MATMUL_BF16X3 (no range limit) when it trips. */
 int mgn_range_check(int32_t* tripped /*host*/, int32_t reset, void* stream);
+/* The same guard without waiting: enqueues, on `stream`, copies of the flag's two words into host_words[0..1] (pinned
+ * host memory that stays valid until the stream has passed this point) and returns.  A non-zero word, read once the
+ * stream has passed (an event recorded after this call), means the flag is up; it stays up until mgn_range_check
+ * resets it, so a training loop (run_train_multiscale.py:137-142) can poll after every step and look at the answer
+ * one step later without ever stalling the host. */
+int mgn_range_poll(int32_t* host_words /*pinned host, 2 words*/, void* stream);
 
 /* ---- host side: edge build (integer work, bit-exact) ------------------------------
  * cells_to_edge_index, core/datasetclass.py:7-20, including what PyG 2.6.1
@@ -224,10 +230,12 @@ int mgn_feature_sums(const float* feat, int64_t rows, int32_t n_feat, double* su
  * forbid hipMalloc.  Same kernels and the same results, bit for bit, as mgn_feature_sums.
  * rows <= MGN_FEATURE_SUMS_STATIC_MAX_ROWS, else MGN_E_CAP.  All calls on one GPU share that GPU's
  * buffer: calls that overlap in time on one GPU (different streams) race; calls on one stream, or
- * ordered by events, do not.  The first call on a device looks up the buffer's address
- * (hipGetSymbolAddress) and must therefore happen outside stream capture. */
+ * ordered by events, do not.  The buffer's address on a device is looked up once (hipGetSymbolAddress), which
+ * cannot happen under stream capture: call mgn_feature_sums_static_prepare() -- it does only that, for the
+ * current device -- before capturing, unless an ordinary call on that device has come first. */
 #define MGN_FEATURE_SUMS_STATIC_MAX_ROWS ((int64_t)1 << 31)
 int mgn_feature_sums_static(const float* feat, int64_t rows, int32_t n_feat, double* sums /*[2F]*/, void* stream);
+int mgn_feature_sums_static_prepare(void);
 
 /* Normalizer state update + statistics (core/normalization.py:34-35, :39-48):
  * if sums != NULL: acc_sum += (float)sums[0:F], acc_sumsq += (float)sums[F:2F];

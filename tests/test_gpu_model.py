@@ -236,7 +236,7 @@ def test_checkpoint_roundtrip(tmp_path):
     assert rel_l2(p1, p2) < 1e-6
 
 
-def test_unsupported_options_raise():
+def test_unsupported_sizes_and_cpu_tensors_raise():
     from gnn_amd.meshgraphnet import EncodeProcessDecodeMultiScale
     with pytest.raises(NotImplementedError):
         EncodeProcessDecodeMultiScale(10, 7, hidden_size=64, sample_ratio=0.0, node_out_dim=3)

@@ -489,6 +489,69 @@ def test_captured_train_step_equals_eager_sequence(options):
     assert o_e.state[next(m_e.parameters())]["step"] == o_c.state[next(m_c.parameters())]["step"] == 7
 
 
+def test_captured_train_step_notices_another_mesh_of_equal_shape():
+    """Frames of a second mesh with the same node and edge counts but other connectivity (the first mesh with its
+    nodes renumbered) must not replay the step captured on the first: after the switch the captured stepper and the
+    eager loop still agree bit for bit, and the stepper has re-captured on the new mesh.  The first mesh's tensors are
+    dropped before the second is built, so that the allocator is free to reuse their addresses."""
+    import gc
+    import numpy as np
+    import gnn_amd
+    from gnn_amd import reorder as R
+    from gnn_amd.optim import FusedAdam
+    from gnn_amd.training import CapturedTrainStep
+    cfg = O.OracleConfig(process_steps=2)
+    sd = O.init_state_dict(cfg, 4)
+
+    def make_batch(shuffle):
+        frames = gnn_amd.synthetic_frames(14, 9, n_frames=5, seed=3)
+        if shuffle is not None:
+            frames = [R.permute_frame(fr, shuffle) for fr in frames]
+        out = []
+        for t in range(4):
+            fr = gnn_amd.MeshGraph(**dict(frames[t].items()))
+            fr["swelling_phi"] = torch.stack([frames[t]["swelling_phi"], frames[t + 1]["swelling_phi"]]).T.contiguous()
+            fr["target"] = torch.cat([frames[t + 1]["world_pos"], frames[t + 1]["phi"]], -1).unsqueeze(0)
+            out.append(fr.to(DEV))                     # device tensors: their addresses are what a stale key would compare
+        return out
+
+    n_nodes = 15 * 10
+    shuffle = np.random.default_rng(1).permutation(n_nodes)
+
+    def run(captured):
+        model = build_model(cfg, sd).train()
+        opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-5, capturable=captured)
+        stepper = CapturedTrainStep(model, opt) if captured else None
+        losses, recaptured = [], False
+        for which in (None, shuffle):
+            batch = make_batch(which)
+            first_graph = stepper.graph if captured else None
+            for fr in batch:
+                if captured:
+                    losses.append(torch.stack(stepper(fr)))
+                else:
+                    opt.zero_grad()
+                    out = model.loss(fr)
+                    out[0].backward()
+                    opt.step()
+                    losses.append(torch.stack([o.detach() for o in out]))
+            if captured and which is not None:
+                recaptured = stepper.graph is not None and stepper.graph is not first_graph
+            del batch, fr
+            gc.collect()
+            torch.cuda.empty_cache()
+        if captured:
+            assert recaptured
+            stepper.close()
+        return model, torch.stack(losses)
+
+    m_e, l_e = run(False)
+    m_c, l_c = run(True)
+    assert torch.equal(l_e, l_c), (l_e, l_c)
+    for (k, p), (_, q) in zip(m_e.named_parameters(), m_c.named_parameters()):
+        assert torch.equal(p, q), k
+
+
 def test_training_step_is_additive_over_disconnected_meshes():
     """A size-independent property at the size of the training configuration (500 x 500 nodes, here twice, three
     blocks): the loss sums over nodes, so on the block-diagonal union of a frame A and a different frame B the loss and

@@ -50,3 +50,29 @@ def test_static_sums_reject_oversize_and_bad_arguments():
     assert lib.mgn_feature_sums_static(feat.data_ptr(), 4, 4, None, None) == -1
     torch.cuda.synchronize()
     assert float(sums.abs().sum()) == 0.0
+
+
+def test_static_sums_inside_a_captured_graph():
+    """The use the entry point exists for: called under HIP graph capture (after the one-time address look-up) and
+    replayed on new data, it gives the sums of the workspace version."""
+    from gnn_amd import ops
+    ops.feature_sums_static_prepare()
+    g = torch.Generator().manual_seed(9)
+    feat = torch.randn(50_000, 10, generator=g).cuda()
+    out = torch.zeros(20, dtype=torch.float64, device="cuda")
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.feature_sums_static(feat, out)             # warm-up outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.feature_sums_static(feat, out)
+    for seed in (10, 11):
+        feat.copy_(torch.randn(50_000, 10, generator=torch.Generator().manual_seed(seed)))
+        graph.replay()
+        ref = torch.empty(20, dtype=torch.float64, device="cuda")
+        scratch = torch.empty(ops.feature_sums_scratch_bytes(50_000, 10), dtype=torch.uint8, device="cuda")
+        ops.feature_sums(feat, ref, scratch)
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref)
