@@ -1,11 +1,16 @@
 """Coarse graph of the multiscale option (core/meshgraphnet.py:237-283): farthest-point sampling of the mesh
-nodes and a k-nearest-neighbour graph over the sample.  Host-side topology preparation, like the edge build; the
-arithmetic on the coarse graph (edge features, encoder, processor blocks) runs in the HIP kernels.
+nodes and a k-nearest-neighbour graph over the sample.  For a mesh that lives on the GPU both run in the library
+(``mgn_fps``, ``mgn_knn_graph``) and the graph never leaves the device; the two host functions of this module are the
+same definitions for CPU tensors (like the host edge build) and give the same indices.  The arithmetic on the coarse
+graph (edge features, encoder, processor blocks) runs in the HIP kernels either way.
 
 The reference rebuilds this graph inside every ``forward`` with a random first sample (:248); here a graph is
 cached per (mesh, first sample), so a fixed first sample (``model.coarse_start``) costs the build once.
 ``knn_graph`` comes from torch-cluster in the reference (absent in this image, no vector pins it): restated as
-"k nearest other points, nearest first, ties by lower index, edges (neighbour -> point) grouped by point"."""
+"k nearest other points, nearest first, ties by lower index, edges (neighbour -> point) grouped by point".
+
+A block-diagonal batch of meshes (``batch_sizes``) is sampled and connected block by block, so every block gets the
+coarse graph it would get alone."""
 from __future__ import annotations
 
 import numpy as np
@@ -53,20 +58,49 @@ def knn_graph(points: torch.Tensor, k: int) -> torch.Tensor:
     return torch.from_numpy(np.stack([nb_s[:, :kk].reshape(-1), centre]).astype(np.int64))
 
 
+def sample_and_connect(mesh_pos: torch.Tensor, sample_ratio: float, starts, batch_sizes=None):
+    """(first [M] int64, edge_index [2, Ec] int64 in coarse numbering, coarse block sizes): the sampled nodes and their
+    kNN graph, block by block.  ``starts``: the first sample of every block as a row of that block (:248).  On the
+    device of ``mesh_pos``: library kernels for a GPU tensor, the host functions above for a CPU tensor."""
+    from . import ops
+    pts = mesh_pos.detach().to(torch.float32).contiguous()
+    sizes = [int(pts.shape[0])] if batch_sizes is None else [int(b) for b in batch_sizes]
+    if sum(sizes) != pts.shape[0]:
+        raise RuntimeError("coarse graph: batch sizes do not add up to the number of nodes")
+    k = 4 if pts.shape[-1] == 3 else 3                                     # :259
+    counts = [max(1, int(n * sample_ratio)) for n in sizes]                # :261
+    starts = [int(s) for s in starts]
+    if len(starts) != len(sizes) or any(not 0 <= s < n for s, n in zip(starts, sizes)):
+        raise RuntimeError("coarse graph: one first sample per block, inside the block")
+    if pts.is_cuda:
+        first = ops.fps(pts, sizes, counts, starts)
+        return first, ops.knn_graph(pts, first, counts, k), counts
+    firsts, edges, n0, c0 = [], [], 0, 0
+    for n, m, st in zip(sizes, counts, starts):
+        f = farthest_point_sampling(pts[n0: n0 + n], m, st)
+        edges.append(knn_graph(pts[n0: n0 + n][f], k) + c0)
+        firsts.append(f + n0)
+        n0, c0 = n0 + n, c0 + m
+    return torch.cat(firsts), torch.cat(edges, dim=1), counts
+
+
 class CoarseGraph:
     """Sample, its kNN graph in receiver-major order on the device, and the original node ids of the coarse
-    edges' end points (for the edge features, which are built from the fine mesh's fields, :276-281)."""
+    edges' end points (for the edge features, which are built from the fine mesh's fields, :276-281).
+    ``start``: the first sample (row of the mesh), or one per block of ``batch_sizes``."""
 
-    def __init__(self, mesh_pos: torch.Tensor, sample_ratio: float, start: int, device):
-        pts = mesh_pos.detach().to("cpu", torch.float32)
-        k = 4 if pts.shape[-1] == 3 else 3
-        n_coarse = max(1, int(pts.shape[0] * sample_ratio))
-        self.start = int(start)
-        self.first_cpu = farthest_point_sampling(pts, n_coarse, start)
-        self.edge_index = knn_graph(pts[self.first_cpu], k)                # coarse numbering
-        self.num_nodes = n_coarse
-        self.first = self.first_cpu.to(device)                             # int64, for row gather / scatter
-        self.topology = Topology(self.edge_index, n_coarse, device)
+    def __init__(self, mesh_pos: torch.Tensor, sample_ratio: float, start, device, batch_sizes=None):
+        starts = [int(s) for s in start] if isinstance(start, (list, tuple)) else [int(start)] * (len(batch_sizes) if batch_sizes else 1)
+        self.start = starts[0] if len(starts) == 1 else tuple(starts)
+        first, self.edge_index, counts = sample_and_connect(mesh_pos, sample_ratio, starts, batch_sizes)
+        n_coarse = sum(counts)
+        self.num_nodes, self.block_sizes = n_coarse, counts
+        self.first = first.to(device)                                      # int64, for row gather / scatter
+        self.topology = Topology(self.edge_index.to(device) if first.is_cuda else self.edge_index, n_coarse, device)
         first32 = self.first.to(torch.int32)
         self.sender_orig = first32[self.topology.sender.long()].contiguous()
         self.recv_orig = first32[self.topology.recv.long()].contiguous()
+
+    @property
+    def first_cpu(self) -> torch.Tensor:
+        return self.first.cpu()

@@ -7,7 +7,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip", "mgn_halo.hip", "mgn_host.cpp"]
+SOURCES = ["mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip", "mgn_halo.hip", "mgn_coarse.hip", "mgn_host.cpp"]
 OUT = os.path.join(PKG, "libmgn_hip.so")
 
 
@@ -26,11 +26,8 @@ def needs_build() -> bool:
     return newest > os.path.getmtime(OUT)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return OUT
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", OUT] + [os.path.join(HERE, s) for s in SOURCES]
+def _compile(src: str, obj: str, verbose: bool) -> None:
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)
@@ -38,6 +35,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
     if verbose:
         print(res.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """One object per translation unit under ``_obj/`` (recompiled when the source or any header is newer), the
+    units compiled side by side, then one link."""
+    if not force and not needs_build():
+        return OUT
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "_obj")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    headers.append(os.path.join(PKG, "..", "include", "mgn_hip.h"))
+    newest_header = max(os.path.getmtime(h) for h in headers)
+    jobs, objs = [], []
+    for s in SOURCES:
+        src, obj = os.path.join(HERE, s), os.path.join(objdir, s + ".o")
+        objs.append(obj)
+        if force or verbose or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), newest_header):
+            jobs.append((src, obj))
+    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
+        for fut in [pool.submit(_compile, src, obj, verbose) for src, obj in jobs]:
+            fut.result()
+    res = subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", OUT] + objs,
+                         cwd=HERE, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc link failed:\n" + res.stdout + res.stderr)
     return OUT
 
 

@@ -319,29 +319,50 @@ class EncodeProcessDecodeMultiScale(nn.Module):
                     self.__dict__["_weights_frozen"] = None
         return scope()
 
-    def _coarse_graph(self, mesh_pos):
+    def _coarse_graph(self, graph):
+        """Coarse graph of the frame's mesh (of every block of a batched frame, ``graph["batch_sizes"]``)."""
         from .coarse import CoarseGraph
+        mesh_pos = graph["mesh_pos"]
+        sizes = tuple(int(b) for b in graph["batch_sizes"]) if "batch_sizes" in graph else None
         start = self.__dict__.get("coarse_start")
         n = mesh_pos.shape[0]
         if start is None:                         # the reference's draw (core/meshgraphnet.py:248), same call on the same device
-            return CoarseGraph(mesh_pos, self.sample_ratio, int(torch.randint(0, n, (1,), device=mesh_pos.device)), mesh_pos.device)
-        key = (mesh_pos.data_ptr(), mesh_pos._version, n, str(mesh_pos.device), int(start), float(self.sample_ratio))
+            starts = [int(torch.randint(0, b, (1,), device=mesh_pos.device)) for b in (sizes or (n,))]
+            return CoarseGraph(mesh_pos, self.sample_ratio, starts, mesh_pos.device, sizes)
+        key = (mesh_pos.data_ptr(), mesh_pos._version, n, str(mesh_pos.device), int(start), float(self.sample_ratio), sizes)
         hit = self.__dict__.get("_coarse")
         if hit is None or hit[0] != key:
-            hit = (key, CoarseGraph(mesh_pos, self.sample_ratio, int(start), mesh_pos.device), mesh_pos)
+            hit = (key, CoarseGraph(mesh_pos, self.sample_ratio, int(start), mesh_pos.device, sizes), mesh_pos)
             self.__dict__["_coarse"] = hit
         return hit[1]
 
-    def _coarse_workspace(self, device, cg):
-        n, nc, ec = self.__dict__["_ws"].x.shape[0], cg.num_nodes, cg.topology.num_edges
+    def _coarse_partition(self, halo, mesh_local):
+        """Coarse graph of a partitioned mesh: the same on every rank, cut along the ranks' node ranges
+        (``partition.CoarsePartition``).  The first sample of an unpinned model is rank 0's draw."""
+        from .partition import CoarsePartition
+        start = self.__dict__.get("coarse_start")
+        if start is None:
+            draw = torch.zeros(1, dtype=torch.float64, device=mesh_local.device)
+            if halo.rank == 0:
+                draw += float(torch.randint(0, halo.global_nodes, (1,)))
+            return CoarsePartition(halo, mesh_local, self.sample_ratio, int(halo.all_reduce_(draw)))
+        key = (id(halo), mesh_local.data_ptr(), mesh_local._version, int(start), float(self.sample_ratio))
+        hit = self.__dict__.get("_coarse")
+        if hit is None or hit[0] != key:
+            hit = (key, CoarsePartition(halo, mesh_local, self.sample_ratio, int(start)), mesh_local, halo)
+            self.__dict__["_coarse"] = hit
+        return hit[1]
+
+    def _coarse_workspace(self, device, cg, n_own):
+        nc, ec = cg.num_nodes, cg.topology.num_edges
         cw = self.__dict__.get("_cws")
-        if cw is None or cw.key != (str(device), n, nc, ec):
+        if cw is None or cw.key != (str(device), n_own, nc, ec):
             f32 = dict(dtype=torch.float32, device=device)
             cw = type("CoarseWorkspace", (), {})()
-            cw.key = (str(device), n, nc, ec)
+            cw.key = (str(device), n_own, nc, ec)
             cw.x, cw.ps, cw.pr, cw.aggr = (torch.empty(nc, H, **f32) for _ in range(4))
             cw.e, cw.edge_feat = torch.empty(ec, H, **f32), torch.empty(ec, 7, **f32)
-            cw.map_back, cw.hidden = torch.empty(n, H, **f32), torch.empty(n, H, **f32)
+            cw.map_back, cw.hidden = torch.empty(n_own, H, **f32), torch.empty(n_own, H, **f32)
             self.__dict__["_cws"] = cw
         return cw
 
@@ -389,16 +410,23 @@ class EncodeProcessDecodeMultiScale(nn.Module):
                                             self.edge_features_normalizer, ws.edge_feat)
         ops.encode(ws.node_feat[:n_own], ms_n, self.node_encoder.weights(), ws.x[:n_own])
         ops.encode(ws.edge_feat, ms_e, self.edge_encoder.weights(), ws.e)
-        cg = cw = None
+        cg = cw = chalo = None
         if self.sample_ratio > 0:                 # core/meshgraphnet.py:179-182
-            if halo is not None:
-                raise NotImplementedError("the coarse multiscale branch is not combined with mesh partitioning")
-            cg = self._coarse_graph(graph["mesh_pos"])
-            cw = self._coarse_workspace(dev, cg)
-            ops.edge_features(world, mesh, phi, cg.sender_orig, cg.recv_orig, cw.edge_feat)
-            ms_c = self.coarse_edge_features_normalizer.stats_for(cw.edge_feat, True)
+            if halo is not None:                  # the coarse graph has its own plan over the ranks' node ranges
+                cg = self._coarse_partition(halo, graph["mesh_pos"])
+                chalo = cg.plan
+                (cworld, cphi), cmesh = cg.state(world, phi), cg.mesh
+                c_snd, c_rcv, c_first, nc_own = cg.topology.sender, cg.topology.recv, cg.first_local, cg.num_owned
+            else:                                 # end points addressed by their mesh node ids
+                cg = self._coarse_graph(graph)
+                cworld, cphi, cmesh = world, phi, mesh
+                c_snd, c_rcv, c_first, nc_own = cg.sender_orig, cg.recv_orig, cg.first, cg.num_nodes
+            cw = self._coarse_workspace(dev, cg, n_own)
+            ops.edge_features(cworld, cmesh, cphi, c_snd, c_rcv, cw.edge_feat)
+            ms_c = self.coarse_edge_features_normalizer.stats_for(cw.edge_feat, True,
+                                                                  chalo.sum_hook("edge") if chalo is not None else None)
             ops.encode(cw.edge_feat, ms_c, self.coarse_edge_encoder.weights(), cw.e)
-            ops.gather_rows(ws.x, cg.first, cw.x)          # encoder output of the sampled nodes (:182)
+            ops.gather_rows(ws.x, c_first, cw.x[:nc_own])  # encoder output of the sampled nodes (:182)
         blocks = list(self.processors)
         # prepared weight sets (one conversion launch per call: a snapshot of the parameters, so never stale)
         use_pk = ops.matmul_mode() == "f16x2" and os.environ.get("MGN_PACKED_WEIGHTS", "1") != "0"
@@ -413,11 +441,11 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             cpk = self._packed("_cpk", cblocks) if use_pk and cblocks else None
             for i, proc in enumerate(cblocks):
                 last = i + 1 == len(cblocks)
-                proc.step_csr(cw.x, cw.e, cg.topology, cw.ps, cw.pr, cw.aggr, None, projected=i > 0,
+                proc.step_csr(cw.x, cw.e, cg.topology, cw.ps, cw.pr, cw.aggr, chalo, projected=i > 0,
                               next_block=None if last else cblocks[i + 1], store_edges=not last,
                               packed=(cpk.edge[i], cpk.node[i]) if cpk is not None else None)
             cw.map_back.zero_()
-            ops.scatter_rows(cw.x, cg.first, cw.map_back)
+            ops.scatter_rows(cw.x[:nc_own], c_first, cw.map_back)
         return ws, topo
 
     # ----------------------------------------------------------------- reference API

@@ -559,6 +559,68 @@ def halo_unpack_state(recv_buf, n_owned, world_local, phi_local):
     _lib.check(rc, "mgn_halo_unpack_state")
 
 
+# --------------------------------------------------------------------------- device: coarse graph (multiscale option)
+FPS_REGISTER_MAX = 16384          # blocks up to this size need no distance workspace
+
+
+def _block_ptr(sizes, device) -> torch.Tensor:
+    ptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(sizes, dtype=np.int64), out=ptr[1:])
+    if ptr[-1] >= 2 ** 31:
+        raise RuntimeError("coarse graph: more than 2^31 rows in one batch")
+    return torch.from_numpy(ptr.astype(np.int32)).to(device)
+
+
+def fps(points, block_sizes, sample_counts, starts) -> torch.Tensor:
+    """Farthest-point sampling of every block of a block-diagonal batch (``mgn_fps``): ``points`` [N, 2 or 3] float32 on
+    the GPU, block b = the next ``block_sizes[b]`` rows, sampled ``sample_counts[b]`` times starting from its row
+    ``starts[b]``.  Returns the sampled rows (global ids, int64), block after block."""
+    n, dim = points.shape
+    sizes, counts = [int(s) for s in block_sizes], [int(c) for c in sample_counts]
+    if sum(sizes) != n or len(counts) != len(sizes) or len(starts) != len(sizes):
+        raise RuntimeError("fps: block sizes must add up to the number of points, one sample count and start per block")
+    for s, c, st in zip(sizes, counts, starts):
+        if c < 0 or (c > 0 and not 0 <= int(st) < s):
+            raise RuntimeError(f"fps: first sample {int(st)} outside a block of {s} points")
+    dev = points.device
+    out = torch.empty(sum(counts), dtype=torch.int64, device=dev)
+    if not sizes or out.numel() == 0:
+        return out
+    biggest = max(sizes)
+    ws = torch.empty(n, dtype=torch.float32, device=dev) if biggest > FPS_REGISTER_MAX else None
+    node_ptr, samp_ptr = _block_ptr(sizes, dev), _block_ptr(counts, dev)
+    first = torch.tensor([int(s) for s in starts], dtype=torch.int32).to(dev)
+    rc = _lib.lib().mgn_fps(_dev(points, torch.float32, (n, dim), "points"), dim, node_ptr.data_ptr(), samp_ptr.data_ptr(),
+                            first.data_ptr(), len(sizes), biggest, _opt(ws, torch.float32, (n,), "dist_ws"), out.data_ptr(),
+                            _stream())
+    _lib.check(rc, "mgn_fps")
+    return out
+
+
+def knn_graph(points, first, coarse_sizes, k: int) -> torch.Tensor:
+    """k-nearest-neighbour graph inside every block of sampled points (``mgn_knn_graph``): the coarse points of block b
+    are the rows ``first[...]`` of ``points`` (``first`` None: the rows themselves), ``coarse_sizes[b]`` of them.
+    Returns ``edge_index`` [2, E] int64 in coarse numbering: row 0 = neighbour (sender), row 1 = point (receiver)."""
+    n, dim = points.shape
+    sizes = [int(s) for s in coarse_sizes]
+    m = sum(sizes)
+    if (first is None and m != n) or (first is not None and first.shape[0] != m):
+        raise RuntimeError("knn_graph: block sizes must add up to the number of coarse points")
+    dev = points.device
+    per_point = [min(int(k), max(s - 1, 0)) for s in sizes]
+    eptr = np.zeros(len(sizes) + 1, dtype=np.int64)
+    np.cumsum(np.asarray([s * kk for s, kk in zip(sizes, per_point)], dtype=np.int64), out=eptr[1:])
+    out = torch.empty(2, int(eptr[-1]), dtype=torch.int64, device=dev)
+    if out.numel() == 0:
+        return out
+    cptr, eptr_dev = _block_ptr(sizes, dev), torch.from_numpy(eptr).to(dev)
+    rc = _lib.lib().mgn_knn_graph(_dev(points, torch.float32, (n, dim), "points"), dim, _opt(first, torch.int64, (m,), "first"),
+                                  cptr.data_ptr(), eptr_dev.data_ptr(), len(sizes), max(sizes), int(k), out[0].data_ptr(),
+                                  out[1].data_ptr(), _stream())
+    _lib.check(rc, "mgn_knn_graph")
+    return out
+
+
 # --------------------------------------------------------------------------- device: training blocks
 _MODES = ("f32", "bf16x3", "f16x2")
 

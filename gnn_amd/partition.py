@@ -33,16 +33,18 @@ def node_bounds(num_nodes: int, world_size: int) -> List[int]:
 class HaloPlan:
     """Everything rank ``rank`` needs to run its share of a partitioned mesh."""
 
-    def __init__(self, edge_index: np.ndarray, num_nodes: int, world_size: int, rank: int):
+    def __init__(self, edge_index: np.ndarray, num_nodes: int, world_size: int, rank: int, bounds=None):
         """From the global edge list (every rank scans all of it; use :meth:`from_local` when a rank can
-        produce its own part of the mesh)."""
+        produce its own part of the mesh).  ``bounds``: the ascending node-range limits [world_size + 1] when the
+        ranges are not the equal split of :func:`node_bounds`."""
         ei = np.asarray(edge_index, dtype=np.int64)
-        bounds = node_bounds(num_nodes, world_size)
+        bounds = node_bounds(num_nodes, world_size) if bounds is None else [int(b) for b in bounds]
         lo, hi = bounds[rank], bounds[rank + 1]
         snd, rcv = ei[0], ei[1]
         mine = (rcv >= lo) & (rcv < hi)
         leaving = (snd >= lo) & (snd < hi) & ~mine
-        self._build(ei[:, mine], np.nonzero(mine)[0], ei[:, leaving], int(num_nodes), int(ei.shape[1]), world_size, rank)
+        self._build(ei[:, mine], np.nonzero(mine)[0], ei[:, leaving], int(num_nodes), int(ei.shape[1]), world_size, rank,
+                    bounds)
 
     @classmethod
     def from_local(cls, in_edges: np.ndarray, out_edges: np.ndarray, num_nodes: int, num_edges: int, world_size: int,
@@ -57,9 +59,12 @@ class HaloPlan:
                     np.asarray(out_edges, dtype=np.int64), int(num_nodes), int(num_edges), world_size, rank)
         return plan
 
-    def _build(self, in_edges, in_edge_ids, out_edges, num_nodes, num_edges, world_size, rank):
+    def _build(self, in_edges, in_edge_ids, out_edges, num_nodes, num_edges, world_size, rank, bounds=None):
         self.world_size, self.rank, self.global_nodes, self.global_edges = world_size, rank, num_nodes, num_edges
-        self.bounds = node_bounds(num_nodes, world_size)
+        self.bounds = node_bounds(num_nodes, world_size) if bounds is None else list(bounds)
+        if (len(self.bounds) != world_size + 1 or self.bounds[0] != 0 or self.bounds[-1] != num_nodes
+                or any(a > b for a, b in zip(self.bounds, self.bounds[1:]))):
+            raise ValueError("HaloPlan: bounds must ascend from 0 to the number of nodes, one range per rank")
         lo, hi = self.bounds[rank], self.bounds[rank + 1]
         owner_of = lambda ids: np.searchsorted(np.asarray(self.bounds[1:]), ids, side="right")
         ls, lr = in_edges[0], in_edges[1]
@@ -320,15 +325,61 @@ class HaloPlan:
             return total
         return hook
 
+    def _all_gather(self, parts, local_rows):
+        """Third transport primitive: every rank's ``local_rows`` into ``parts`` (one tensor per rank)."""
+        if self._host_staged(local_rows):
+            host = [p.cpu() for p in parts]
+            dist.all_gather(host, local_rows.cpu(), group=self.group)
+            for p, h in zip(parts, host):
+                p.copy_(h)
+        else:
+            dist.all_gather(parts, local_rows, group=self.group)
+
     def gather_owned(self, local_rows: torch.Tensor) -> torch.Tensor:
-        """All ranks' owned rows concatenated in global node order (for outputs / tests).
+        """All ranks' owned rows concatenated in global node order (outputs, the coarse graph of a partitioned mesh).
         ``local_rows`` is [num_owned, ...]."""
         if self.world_size == 1:
             return local_rows
         sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(self.world_size)]
         parts = [local_rows.new_empty((s,) + tuple(local_rows.shape[1:])) for s in sizes]
-        dist.all_gather(parts, local_rows.contiguous(), group=self.group)
+        self._all_gather(parts, local_rows.contiguous())
         return torch.cat(parts, dim=0)
+
+
+class CoarsePartition:
+    """The coarse graph of the multiscale option (core/meshgraphnet.py:237-283) on a partitioned mesh.
+
+    Sampling is a sequential walk over the whole mesh, so every rank gathers the mesh coordinates once (8 bytes per
+    node) and runs the same sampling and nearest-neighbour kernels: all ranks hold the same coarse graph.  A coarse
+    node belongs to the rank that owns its mesh node; renumbered by ascending mesh node id the coarse nodes of a rank
+    are one contiguous range, and the coarse blocks run on a second :class:`HaloPlan` over those ranges (the
+    neighbours of a coarse node may lie anywhere, so this plan's halo is its own; renumbering keeps the order of a
+    receiver's in-edges, hence the order of every sum).  Per step the coarse end points' state travels through that
+    plan like the fine state does."""
+
+    def __init__(self, plan: HaloPlan, mesh_local: torch.Tensor, sample_ratio: float, start: int):
+        from .coarse import sample_and_connect
+        dev = mesh_local.device
+        mesh_global = plan.gather_owned(mesh_local[: plan.num_owned].to(torch.float32).contiguous())
+        first, ei, counts = sample_and_connect(mesh_global, sample_ratio, [int(start)])
+        m = counts[0]
+        first_sorted, order = torch.sort(first)                   # new coarse id -> mesh node / id in sampling order
+        new_id = torch.empty_like(order)
+        new_id[order] = torch.arange(m, device=order.device)
+        bounds_c = torch.searchsorted(first_sorted, torch.tensor(plan.bounds, dtype=torch.int64, device=first.device)).tolist()
+        self.start, self.num_global, self.edges_global = int(start), m, int(ei.shape[1])
+        self.plan = plan.__class__(new_id[ei].cpu().numpy(), m, plan.world_size, plan.rank, bounds=bounds_c).to(dev, plan.group)
+        lo_c, hi_c = bounds_c[plan.rank], bounds_c[plan.rank + 1]
+        # rows of the rank's fine arrays that are coarse nodes, in coarse order (int64 for row gather / scatter)
+        self.first_local = (first_sorted[lo_c:hi_c] - plan.bounds[plan.rank]).to(dev).contiguous()
+        ids = torch.from_numpy(self.plan.local_node_ids).to(first_sorted.device)
+        self.mesh = mesh_global[first_sorted[ids]].to(dev).contiguous()        # coordinates of the local coarse rows
+        self.topology = self.plan.topology
+        self.num_nodes, self.num_owned = self.plan.num_local, self.plan.num_owned
+
+    def state(self, world: torch.Tensor, phi: torch.Tensor):
+        """(world_pos, phi) of the local coarse rows [owned | halo] from the rank's fine arrays."""
+        return self.plan.exchange_state(world[self.first_local], phi[self.first_local])
 
 
 def all_reduce_gradients(model, group=None, average: bool = True) -> None:

@@ -111,6 +111,8 @@ def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
     with torch.no_grad(), frozen:
         static = MeshGraph(mesh_pos=first["mesh_pos"], node_type=first["node_type"], mat_param=first["mat_param"],
                            edge_index=first["edge_index"]).to(device)
+        if "batch_sizes" in first:                # block-diagonal batch: the coarse branch samples every block on its own
+            static["batch_sizes"] = first["batch_sizes"]
         # swelling schedule [T + time_dim, N], zero past the end (rollout.py:17-26)
         sched = torch.stack([data[t]["swelling_phi"] for t in range(n_frames)]
                             + [torch.zeros_like(first["swelling_phi"])] * time_dim).to(device)
@@ -183,12 +185,10 @@ def rollout_batched(model, trajectories, progress: bool = False):
     way small meshes fill the GPU) and returns one result dictionary per trajectory, each with
     the layout of :func:`rollout`.  The normalisers see one accumulation per step over all
     blocks instead of one per trajectory and step; with statistics that no longer accumulate
-    the per-trajectory results are identical to separate :func:`rollout` calls."""
+    the per-trajectory results are identical to separate :func:`rollout` calls.  With the coarse multiscale branch every
+    block is sampled and connected on its own (``model.coarse_start`` is the first sample inside each block), so no
+    coarse edge ties two trajectories together."""
     trajectories = list(trajectories)
-    if getattr(model, "sample_ratio", 0) > 0 and len(trajectories) > 1:
-        # the coarse graph is built from the coordinates of the union: sampling and nearest neighbours would tie
-        # the trajectories (which share their mesh coordinates) to one another
-        raise NotImplementedError("rollout_batched: not with the coarse multiscale branch (sample_ratio > 0)")
     n_frames = len(trajectories[0])
     if any(len(tr) != n_frames for tr in trajectories):
         raise ValueError("rollout_batched: trajectories must have the same number of frames")

@@ -183,25 +183,31 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
     if model.sample_ratio > 0:
         # coarse branch (core/meshgraphnet.py:179-194): its edge latents from the fine fields of the coarse end points,
         # its node latents = the encoder output of the sampled nodes
-        if halo is not None:
-            raise NotImplementedError("the coarse multiscale branch is not combined with mesh partitioning")
-        cg = model._coarse_graph(graph["mesh_pos"])
-        nc, ec = cg.num_nodes, cg.topology.num_edges
+        if halo is not None:                       # partitioned: the coarse graph runs on its own plan
+            cg = model._coarse_partition(halo, graph["mesh_pos"])
+            chalo = cg.plan
+            (cworld, cphi), cmesh = cg.state(world, phi), cg.mesh
+            c_snd, c_rcv, c_first, nc, nc_loc = cg.topology.sender, cg.topology.recv, cg.first_local, cg.num_owned, cg.num_nodes
+        else:
+            cg, chalo = model._coarse_graph(graph), None
+            cworld, cphi, cmesh = world, phi, mesh
+            c_snd, c_rcv, c_first, nc, nc_loc = cg.sender_orig, cg.recv_orig, cg.first, cg.num_nodes, cg.num_nodes
+        ec = cg.topology.num_edges
         efeat_c = torch.empty(ec, 7, dtype=torch.float32, device=dev)
-        ops.edge_features(world, mesh, phi, cg.sender_orig, cg.recv_orig, efeat_c)
-        ms_c = model.coarse_edge_features_normalizer.stats_for(efeat_c, True)
+        ops.edge_features(cworld, cmesh, cphi, c_snd, c_rcv, efeat_c)
+        ms_c = model.coarse_edge_features_normalizer.stats_for(efeat_c, True, chalo.sum_hook("edge") if chalo is not None else None)
         ecf_pad = _empty(ec, dev)
         ops.train_pad_features(efeat_c, ms_c, ecf_pad)
         elc, enc_c = encoder(model.coarse_edge_encoder, ecf_pad)
         xc = _empty(nc, dev)
-        ops.gather_rows(x, cg.first, xc)
+        ops.gather_rows(x, c_first, xc)
     x, layers = run_blocks(list(model.processors), x, el, topo, n, n_loc, e, halo)
     map_back = None
     if model.sample_ratio > 0:
-        xc, layers_c = run_blocks(list(model.coarse_processors), xc, elc, cg.topology, nc, nc, ec, None)
+        xc, layers_c = run_blocks(list(model.coarse_processors), xc, elc, cg.topology, nc, nc_loc, ec, chalo)
         map_back = torch.zeros(n, H, dtype=torch.float32, device=dev)
-        ops.scatter_rows(xc, cg.first, map_back)                      # :192-193
-        coarse = dict(cg=cg, enc_c=enc_c, layers=layers_c)
+        ops.scatter_rows(xc, c_first, map_back)                      # :192-193
+        coarse = dict(cg=cg, enc_c=enc_c, layers=layers_c, halo=chalo, first=c_first, nc=nc, nc_loc=nc_loc, ec=ec)
 
     dec = model.node_decoder
     hd, decoded = _empty(n, dev), _empty(n, dev)
@@ -342,15 +348,14 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
 
     gec = None
     if coarse is not None:
-        cg = coarse["cg"]
-        nc, ec = cg.num_nodes, cg.topology.num_edges
+        cg, nc, nc_loc, ec, c_first = coarse["cg"], coarse["nc"], coarse["nc_loc"], coarse["ec"], coarse["first"]
         gxc = _empty(nc, dev)
-        ops.gather_rows(gmap, cg.first, gxc)          # rows of the mapped-back tensor that came from the coarse nodes
+        ops.gather_rows(gmap, c_first, gxc)           # rows of the mapped-back tensor that came from the coarse nodes
         gec, g2ec, g1ec, _, _ = blocks_backward(list(model.coarse_processors), "coarse_processors", coarse["layers"], cg.topology,
-                                                None, gxc, nc, nc, ec)
+                                                coarse["halo"], gxc, nc, nc_loc, ec)
     ge, g2e, g1e, g2n, g1n = blocks_backward(list(model.processors), "processors", saved["layers"], topo, halo, gx, n, n_loc, e)
     if coarse is not None:
-        gx.index_add_(0, cg.first, gxc)               # the coarse nodes' latents are rows of the node encoder's output (:182)
+        gx.index_add_(0, c_first, gxc)                # the coarse nodes' latents are rows of the node encoder's output (:182)
 
     # ---- encoders: y = LN(W1 ReLU(W0 feat + b0) + b1), no gradient wanted for the features
     def encoder_bwd(seq, name, saved_enc, gy, g_a, g_b):

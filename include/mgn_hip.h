@@ -440,6 +440,34 @@ int mgn_halo_stage_state(const float* world_pos, const float* phi, int64_t n_own
                          float* world_local, float* phi_local, float* send_buf, void* stream);
 int mgn_halo_unpack_state(const float* recv_buf, int64_t n_halo, float* world_halo, float* phi_halo, void* stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Coarse graph of the multiscale option (core/meshgraphnet.py:237-283), built where the mesh lives.  Both entry points
+ * take a block-diagonal batch: block b holds the points [node_ptr[b], node_ptr[b+1]) and is sampled / connected on its
+ * own (a single mesh is one block).  All arrays are device memory; neither call synchronises or allocates.
+ *
+ * mgn_fps: farthest-point sampling (:243-254, called at :262).  Writes the sampled point ids (global rows of `points`)
+ *   of block b to out_idx[sample_ptr[b] .. sample_ptr[b+1]), the first being node_ptr[b] + starts[b] (the reference
+ *   draws it with torch.randint, :248), each further one torch.argmax of the running minimum of
+ *   torch.norm(points - last, dim=-1): float32, fused multiply-add chain over the coordinates, rounded square root,
+ *   lowest index among equal distances -- the choices of the reference's expressions on the CPU.  A block whose start
+ *   lies outside [0, block size) gets -1 in all its slots.  One 1024-thread workgroup per block; blocks of up to
+ *   16 384 points keep everything in registers, larger ones keep the running distances in dist_ws (one float per
+ *   point of the batch, may be NULL if max_block_nodes <= 16 384).  dim is 2 or 3; coordinates must be finite.
+ *   Cost: (number of samples) rounds over the block's points on one compute unit.
+ * mgn_knn_graph: torch_geometric.nn.knn_graph(sampled_points, k, loop=False) (:268; torch-cluster, absent from the
+ *   reference tree: restated).  The coarse points of block b are rows first[coarse_ptr[b] .. coarse_ptr[b+1]) of
+ *   `points` (first == NULL: the rows themselves).  For every coarse point c the min(k, block size - 1) nearest other
+ *   points of its block, by float64 squared distance (products and sums rounded one by one), nearest first, equal
+ *   distances by lower index; edge j of point c goes to position edge_ptr[b] + (c - coarse_ptr[b]) * kk + j as
+ *   out_sender = neighbour, out_recv = c, both in coarse numbering (positions in `first`).  k in {1, 2, 3, 4, 6, 8}
+ *   (the reference uses 3 in 2-D, 4 in 3-D, :259).  Brute force: (block size)^2 distance evaluations. */
+int mgn_fps(const float* points /*[N][dim]*/, int32_t dim, const int32_t* node_ptr /*[n_blocks+1]*/,
+            const int32_t* sample_ptr /*[n_blocks+1]*/, const int32_t* starts /*[n_blocks]*/, int32_t n_blocks,
+            int64_t max_block_nodes, float* dist_ws /*[N] or NULL*/, int64_t* out_idx, void* stream);
+int mgn_knn_graph(const float* points /*[N][dim]*/, int32_t dim, const int64_t* first /*[M] or NULL*/,
+                  const int32_t* coarse_ptr /*[n_blocks+1]*/, const int64_t* edge_ptr /*[n_blocks+1]*/, int32_t n_blocks,
+                  int64_t max_block_points, int32_t k, int64_t* out_sender, int64_t* out_recv, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

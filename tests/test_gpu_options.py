@@ -57,9 +57,9 @@ def test_options_golden(tag, att, ratio, csteps):
     model.coarse_start = int(d[f"{tag}_start1"])
     f = model.forward(g)
     if ratio > 0:
-        cg = model._coarse_graph(g["mesh_pos"])
+        cg = model._coarse_graph(g)
         assert np.array_equal(cg.first_cpu.numpy(), d[f"{tag}_first1"])
-        assert np.array_equal(cg.edge_index.numpy(), d[f"{tag}_coarse_edge_index1"])
+        assert np.array_equal(cg.edge_index.cpu().numpy(), d[f"{tag}_coarse_edge_index1"])
     model.coarse_start = int(d[f"{tag}_start2"])
     p = model.predict(g)
     print("%s: forward rel-L2 %.3e  predict rel-L2 %.3e" % (tag, rel_l2(f, torch.from_numpy(d[f"{tag}_forward"])), rel_l2(p, torch.from_numpy(d[f"{tag}_predict2"]))))
@@ -390,8 +390,8 @@ def test_attention_backward_entry_points_vs_torch():
 
 
 def test_batched_rollout_with_options():
-    """Block-diagonal batches: attention stays per trajectory (its sums run over a receiver's own in-edges), so a batch
-    equals the separate rollouts; the coarse branch would tie the trajectories together and is refused."""
+    """Block-diagonal batches: attention stays per trajectory (its sums run over a receiver's own in-edges), and the
+    coarse branch samples and connects every block on its own, so a batch equals the separate rollouts."""
     import gnn_amd
     from gnn_amd.rollout import rollout, rollout_batched
     cfg = O.OracleConfig(process_steps=2, attention=True)
@@ -401,10 +401,18 @@ def test_batched_rollout_with_options():
     both = rollout_batched(model, trajs)
     for tr, res in zip(trajs, both):
         assert rel_l2(res["pred"], rollout(model, tr)["pred"]) < 1e-6
-    cfg2 = O.OracleConfig(process_steps=1, sample_ratio=0.5, coarse_process_steps=1)
+    cfg2 = O.OracleConfig(process_steps=2, attention=True, sample_ratio=0.5, coarse_process_steps=2)
     model2 = build(cfg2, O.init_state_dict(cfg2, 3))
-    with pytest.raises(NotImplementedError):
-        rollout_batched(model2, trajs)
+    freeze_to(model2, cfg2, O.make_norms(cfg2))
+    model2.coarse_start = 7
+    trajs2 = [gnn_amd.synthetic_frames(9, 6, n_frames=5, seed=1), gnn_amd.synthetic_frames(12, 8, n_frames=5, seed=2),
+              gnn_amd.synthetic_frames(9, 6, n_frames=5, seed=3)]        # blocks of different meshes
+    both2 = rollout_batched(model2, trajs2)
+    for tr, res in zip(trajs2, both2):
+        alone = rollout(model2, tr)["pred"]
+        assert rel_l2(res["pred"], alone) < 1e-6, rel_l2(res["pred"], alone)
+    model2.coarse_start = None                                            # one draw per block and call: runs, finite
+    assert all(bool(torch.isfinite(r["pred"]).all()) for r in rollout_batched(model2, trajs2))
 
 
 @pytest.mark.parametrize("tag,att,ratio,csteps", [("plain", False, 0.0, 0)] + CASES)

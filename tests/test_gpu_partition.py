@@ -58,6 +58,13 @@ def _thread_plan_class(bus):
             recv.fill_(float("nan"))                  # stale rows must not be read before wait()
             return Pending()
 
+        def _all_gather(self, parts, local_rows):
+            bus.slots[self.rank] = local_rows
+            bus.barrier.wait()
+            for q in range(self.world_size):
+                parts[q].copy_(bus.slots[q])
+            bus.barrier.wait()
+
         def all_reduce_(self, t):
             bus.slots[self.rank] = t.clone()
             bus.barrier.wait()
@@ -73,19 +80,26 @@ def _thread_plan(ei, n, world, rank, bus):
     return _thread_plan_class(bus)(ei, n, world, rank).to(DEV)
 
 
-@pytest.mark.parametrize("world,nx,ny,attention", [(2, 60, 45, False), (3, 60, 45, False), (4, 300, 260, False), (3, 60, 45, True)])
-def test_partitioned_rollout_matches_single_gpu(world, nx, ny, attention):
-    """Also with the attention option: the projected rows of the halo nodes travel like the sender projections."""
+@pytest.mark.parametrize("world,nx,ny,attention,ratio", [(2, 60, 45, False, 0.0), (3, 60, 45, False, 0.0), (4, 300, 260, False, 0.0),
+                                                         (3, 60, 45, True, 0.0), (2, 60, 45, False, 0.5), (3, 50, 37, True, 0.3),
+                                                         (4, 30, 21, False, 0.02)])
+def test_partitioned_rollout_matches_single_gpu(world, nx, ny, attention, ratio):
+    """Also with the attention option (the projected rows of the halo nodes travel like the sender projections) and with
+    the coarse multiscale branch: every rank builds the same coarse graph from the gathered mesh coordinates and runs
+    its share of it on a second plan, whose halo is whatever the nearest-neighbour edges reach (the last case leaves
+    ranks with one or no coarse node)."""
     from gnn_amd import partition
     from gnn_amd.graph import MeshGraph
-    if attention:
+    if attention or ratio > 0:
         from test_gpu_options import build
 
         def build_model(cfg, sd):
-            return build(cfg, sd)
+            m = build(cfg, sd)
+            m.coarse_start = 11
+            return m
     else:
         from test_gpu_model import build_model
-    cfg = O.OracleConfig(process_steps=4, attention=attention)
+    cfg = O.OracleConfig(process_steps=4, attention=attention, sample_ratio=ratio, coarse_process_steps=2 if ratio > 0 else 0)
     sd = O.init_state_dict(cfg, 3)
     g = O.synthetic_graph(nx, ny, seed=5)          # the largest case: 78k nodes, every launch spans many workgroups
     n = g["mesh_pos"].shape[0]
@@ -112,6 +126,9 @@ def test_partitioned_rollout_matches_single_gpu(world, nx, ny, attention):
             model = partition.attach(build_model(cfg, sd), plan)
             gl = plan.local_graph(MeshGraph(**g)).to(DEV)
             results[rank] = run_steps(model, gl)
+            if ratio > 0:                 # an unpinned first sample is rank 0's draw on every rank: runs, finite
+                model.coarse_start = None
+                assert bool(torch.isfinite(model.predict(gl)).all())
         except Exception as exc:          # noqa: BLE001
             errors.append(exc)
             bus.barrier.abort()
@@ -127,21 +144,24 @@ def test_partitioned_rollout_matches_single_gpu(world, nx, ny, attention):
     assert rel_l2(out, ref) < 1e-6, rel_l2(out, ref)
 
 
-@pytest.mark.parametrize("world,attention", [(2, False), (3, False), (3, True)])
-def test_partitioned_training_step_matches_single_gpu(world, attention):
+@pytest.mark.parametrize("world,attention,ratio", [(2, False, 0.0), (3, False, 0.0), (3, True, 0.0), (2, False, 0.5), (3, True, 0.3)])
+def test_partitioned_training_step_matches_single_gpu(world, attention, ratio):
     """loss + backward on a mesh split over ranks: forward halo of the sender projections, reverse
     halo of their gradients, one all-reduce of the loss and of the parameter gradients.  Every rank
-    must end with the single-GPU loss and gradients (sums are grouped differently: 1e-5)."""
+    must end with the single-GPU loss and gradients (sums are grouped differently: 1e-5).  With the coarse
+    branch the same happens once more on the coarse graph's own plan."""
     from gnn_amd import partition
     from gnn_amd.graph import MeshGraph
-    if attention:       # the attn_lin rows of the halo senders travel forward, their gradients back
+    if attention or ratio > 0:       # the attn_lin rows of the halo senders travel forward, their gradients back
         from test_gpu_options import build
 
         def build_model(cfg, sd):
-            return build(cfg, sd).train()
+            m = build(cfg, sd).train()
+            m.coarse_start = 11
+            return m
     else:
         from test_gpu_model import build_model
-    cfg = O.OracleConfig(process_steps=3, attention=attention)
+    cfg = O.OracleConfig(process_steps=3, attention=attention, sample_ratio=ratio, coarse_process_steps=2 if ratio > 0 else 0)
     sd = O.init_state_dict(cfg, 11)
     g = O.synthetic_graph(40, 33, seed=8)
     n = g["mesh_pos"].shape[0]
