@@ -57,6 +57,10 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
     float* D = dist + n0;
     __shared__ __align__(16) float s_v[2][FPS_W];
     __shared__ __align__(16) int s_i[2][FPS_W];
+    // blocks of up to 4096 points also sit in LDS: the winner's coordinates are then an LDS read away instead of a
+    // dependent round trip to L2 (the larger part of a round on a mesh of a few hundred nodes)
+    constexpr int LDS_PTS = (R > 0 && R <= 4) ? R * FPS_T : 1;
+    __shared__ float s_p[LDS_PTS * DIM];
     constexpr int RR = R > 0 ? R : 1;
     float pr[RR][DIM], dr[RR];
     const float inf = __builtin_inff();
@@ -67,7 +71,12 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
             dr[r] = j < n ? inf : -1.f;              // a slot without a point never wins (distances are >= 0)
 #pragma unroll
             for (int k = 0; k < DIM; ++k) pr[r][k] = j < n ? P[(size_t)j * DIM + k] : 0.f;
+            if (LDS_PTS > 1 && j < n) {
+#pragma unroll
+                for (int k = 0; k < DIM; ++k) s_p[j * DIM + k] = pr[r][k];
+            }
         }
+        if (LDS_PTS > 1) __syncthreads();
     } else {
         for (int j = tid; j < n; j += FPS_T) D[j] = inf;
     }
@@ -75,7 +84,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
     for (int it = 1; it < m; ++it) {
         float q[DIM];
 #pragma unroll
-        for (int k = 0; k < DIM; ++k) q[k] = P[(size_t)cur * DIM + k];
+        for (int k = 0; k < DIM; ++k) q[k] = LDS_PTS > 1 ? s_p[cur * DIM + k] : P[(size_t)cur * DIM + k];
         float bv = -1.f;
         int bi = 0x7fffffff;
         if (R > 0) {
@@ -87,14 +96,24 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
                 if (nd > bv) { bv = nd; bi = tid + r * FPS_T; }      // ascending ids per thread: the first maximum stays
             }
         } else {
-            for (int j = tid; j < n; j += FPS_T) {
-                float p[DIM];
+            constexpr int U = 8;                       // loads of eight points in flight per thread
+            for (int j0 = tid; j0 < n; j0 += U * FPS_T) {
+                float p[U][DIM], old[U];
 #pragma unroll
-                for (int k = 0; k < DIM; ++k) p[k] = P[(size_t)j * DIM + k];
-                const float d = fps_distance<DIM>(p, q), old = D[j];
-                const float nd = d < old ? d : old;
-                if (d < old) D[j] = d;
-                if (nd > bv) { bv = nd; bi = j; }
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * FPS_T;
+                    old[u] = j < n ? D[j] : -1.f;
+#pragma unroll
+                    for (int k = 0; k < DIM; ++k) p[u][k] = j < n ? P[(size_t)j * DIM + k] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * FPS_T;
+                    const float d = fps_distance<DIM>(p[u], q);
+                    const float nd = d < old[u] ? d : old[u];
+                    if (j < n && d < old[u]) D[j] = d;
+                    if (nd > bv) { bv = nd; bi = j; }      // ascending ids per thread; a slot past the end holds -1
+                }
             }
         }
 #pragma unroll
