@@ -19,6 +19,11 @@ class MgnMlp(C.Structure):
                 ("ln_w", C.c_void_p), ("ln_b", C.c_void_p)]
 
 
+class MgnReduceRec(C.Structure):
+    _fields_ = [("partial", C.c_void_p), ("out", C.c_void_p), ("vec", C.c_void_p * 3), ("nblocks", C.c_int32),
+                ("stride", C.c_int32), ("mcount", C.c_int32), ("ld", C.c_int32), ("nvec", C.c_int32), ("reserved", C.c_int32)]
+
+
 class MgnWeightSlice(C.Structure):
     _fields_ = [("w", C.c_void_p), ("ld", C.c_int32), ("col0", C.c_int32), ("k", C.c_int32), ("reserved", C.c_int32)]
 
@@ -67,6 +72,9 @@ SIGNATURES = {
     "mgn_gather_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
     "mgn_scatter_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
     "mgn_train_scratch_bytes": (_I64, []),
+    "mgn_train_partial_bytes": (_I64, [_I32, _I64]),
+    "mgn_train_defer_reductions": (C.c_int, [_P, _I32, _P]),
+    "mgn_train_reduce_many": (C.c_int, [_P, _I32, _P]),
     "mgn_train_linear_fwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P, _I64, _P]),
     "mgn_train_ln_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_train_ln_bwd": (C.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _I64, _P]),

@@ -808,6 +808,28 @@ __global__ __launch_bounds__(64) void reduce_partials_kernel(ReduceArgs a) {
     else a.vec[(i - a.mcount) / H][(i - a.mcount) % H] = sum;
 }
 
+// Many such reductions in one launch (blockIdx.y = record): the records travel by value in the kernel arguments.
+constexpr int REDUCE_MANY_MAX = 48;
+struct ReduceManyArgs { MgnReduceRec r[REDUCE_MANY_MAX]; };
+static_assert(sizeof(MgnReduceRec) == 64 && sizeof(ReduceManyArgs) <= 3072, "records must fit the kernel argument segment");
+
+__global__ __launch_bounds__(64) void reduce_many_kernel(ReduceManyArgs a) {
+    const MgnReduceRec& r = a.r[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= r.mcount + r.nvec * H) return;
+    const float* p = r.partial + i;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int b = 0;
+    for (; b + 8 <= r.nblocks; b += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += p[(size_t)(b + k) * r.stride];
+    }
+    for (int k = 0; b < r.nblocks; ++b, ++k) s[k] += p[(size_t)b * r.stride];
+    const float sum = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));     // as reduce_partials_kernel
+    if (i < r.mcount) r.out[(size_t)(i / H) * r.ld + (i % H)] = sum;
+    else r.vec[(i - r.mcount) / H][(i - r.mcount) % H] = sum;
+}
+
 // ------------------------------------------------------------------------ segmented row sums
 __global__ __launch_bounds__(NT) void segment_sum_kernel(const float* __restrict__ src, const int* __restrict__ rowptr,
                                                          const int* __restrict__ order, float* __restrict__ out,
@@ -1008,10 +1030,21 @@ __global__ __launch_bounds__(NT) void adam_dev_kernel(const AdamEntry* __restric
     }
 }
 
-void launch_reduce(const float* partial, int nblocks, int stride, int mcount, int ld, float* out, int nvec, float* v0,
-                   float* v1, float* v2, hipStream_t s) {
+// Deferral of the calling thread (mgn_train_defer_reductions): while a record list is installed, the backward entry
+// points append their reduction to it instead of launching it.
+struct DeferState { MgnReduceRec* recs; int capacity; int32_t* count; };
+thread_local DeferState t_defer = {nullptr, 0, nullptr};
+
+// 0 on success; a full record list is an error of the caller (the reduction is then launched at once, so no result is lost)
+int launch_reduce(const float* partial, int nblocks, int stride, int mcount, int ld, float* out, int nvec, float* v0,
+                  float* v1, float* v2, hipStream_t s) {
+    if (t_defer.recs && *t_defer.count < t_defer.capacity) {
+        t_defer.recs[(*t_defer.count)++] = MgnReduceRec{partial, out, {v0, v1, v2}, nblocks, stride, mcount, ld, nvec, 0};
+        return 0;
+    }
     ReduceArgs r{partial, nblocks, stride, mcount, ld, out, nvec, {v0, v1, v2}};
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((mcount + nvec * H + 63) / 64), dim3(64), 0, s, r);
+    return t_defer.recs ? 1 : 0;
 }
 
 int train_grid(long long rows, int per_cu) { return grid_for((rows + TM - 1) / TM, per_cu); }
@@ -1046,6 +1079,52 @@ int mgn_train_poll_range_flag(int* host_word, void* stream) {
 
 extern "C" int64_t mgn_train_scratch_bytes(void) {
     return (int64_t)TRAIN_BLOCKS_MAX * PARTIAL * (int64_t)sizeof(float);
+}
+
+extern "C" int64_t mgn_train_partial_bytes(int32_t kind, int64_t rows) {
+    if (rows < 0 || kind < 0 || kind > 2) return -1;
+    long long g, stride;
+    if (kind == 0) {                                           // mgn_train_linear_bwd (either matrix path: the larger grid)
+        g = train_grid(rows, 2); stride = PARTIAL;
+        if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX;
+    } else if (kind == 1) {                                    // mgn_train_ln_bwd
+        g = stream_grid(rows, 64); stride = 2 * H;
+        if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX;
+    } else {                                                   // mgn_train_edge_bwd (rows = edges)
+        g = train_grid(rows, 1); stride = PARTIAL_E;
+    }
+    return (int64_t)(g * stride * (long long)sizeof(float));
+}
+
+extern "C" int mgn_train_defer_reductions(MgnReduceRec* recs, int32_t capacity, int32_t* count) {
+    if (recs == nullptr) { t_defer = DeferState{nullptr, 0, nullptr}; return 0; }
+    MGN_REQUIRE(capacity > 0 && count && *count >= 0 && *count <= capacity, "mgn_train_defer_reductions");
+    t_defer = DeferState{recs, (int)capacity, count};
+    return 0;
+}
+
+extern "C" int mgn_train_reduce_many(const MgnReduceRec* recs, int32_t n, void* stream) {
+    MGN_REQUIRE(n >= 0 && (n == 0 || recs), "mgn_train_reduce_many");
+    for (int i = 0; i < n; ++i) {
+        const MgnReduceRec& r = recs[i];
+        MGN_REQUIRE(r.partial && r.nblocks > 0 && r.stride > 0 && r.mcount >= 0 && r.nvec >= 0 && r.nvec <= 3, "mgn_train_reduce_many");
+        MGN_REQUIRE(r.mcount == 0 || (r.out && r.ld >= H), "mgn_train_reduce_many");
+        for (int v = 0; v < r.nvec; ++v) MGN_REQUIRE(r.vec[v], "mgn_train_reduce_many");
+    }
+    for (int first = 0; first < n; first += REDUCE_MANY_MAX) {
+        const int cnt = n - first < REDUCE_MANY_MAX ? n - first : REDUCE_MANY_MAX;
+        ReduceManyArgs a;
+        int widest = 0;
+        for (int i = 0; i < cnt; ++i) {
+            a.r[i] = recs[first + i];
+            const int items = a.r[i].mcount + a.r[i].nvec * H;
+            widest = items > widest ? items : widest;
+        }
+        for (int i = cnt; i < REDUCE_MANY_MAX; ++i) a.r[i] = MgnReduceRec{nullptr, nullptr, {nullptr, nullptr, nullptr}, 0, 0, 0, 0, 0, 0};
+        if (widest == 0) continue;
+        hipLaunchKernelGGL(reduce_many_kernel, dim3((widest + 63) / 64, cnt), dim3(64), 0, (hipStream_t)stream, a);
+    }
+    return check_launch("mgn_train_reduce_many");
 }
 
 extern "C" int mgn_train_linear_fwd(const float* A, const float* B, const float* W, int32_t ldw, int32_t koff_a,
@@ -1091,7 +1170,8 @@ extern "C" int mgn_train_ln_bwd(const float* G, const float* Gg, const int32_t* 
     if (g > TRAIN_BLOCKS_MAX) g = TRAIN_BLOCKS_MAX;
     hipLaunchKernelGGL(train_ln_bwd_kernel, dim3(g), dim3(NT), 0, (hipStream_t)stream, G, Gg, idx, v, gamma,
                        relu_mask, gpre, (float*)scratch, (long long)rows);
-    launch_reduce((const float*)scratch, g, 2 * H, 0, 0, nullptr, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
+    if (launch_reduce((const float*)scratch, g, 2 * H, 0, 0, nullptr, 2, dgamma, dbeta, nullptr, (hipStream_t)stream))
+        { mgn_set_error("mgn_train_ln_bwd: the deferred-reduction list is full"); return MGN_E_CAP; }
     return check_launch("mgn_train_ln_bwd");
 }
 
@@ -1116,7 +1196,8 @@ extern "C" int mgn_train_linear_bwd(const float* G, const float* A, const float*
     } else if (GA && dW) hipLaunchKernelGGL((train_linear_bwd_kernel<true, true>), dim3(g), dim3(NT), 0, s, a);
     else if (GA) hipLaunchKernelGGL((train_linear_bwd_kernel<true, false>), dim3(g), dim3(NT), 0, s, a);
     else hipLaunchKernelGGL((train_linear_bwd_kernel<false, true>), dim3(g), dim3(NT), 0, s, a);
-    if (dW) launch_reduce((const float*)scratch, g, PARTIAL, PARTIAL_W, lddw, dW, db ? 1 : 0, db, nullptr, nullptr, s);
+    if (dW && launch_reduce((const float*)scratch, g, PARTIAL, PARTIAL_W, lddw, dW, db ? 1 : 0, db, nullptr, nullptr, s))
+        { mgn_set_error("mgn_train_linear_bwd: the deferred-reduction list is full"); return MGN_E_CAP; }
     return check_launch("mgn_train_linear_bwd");
 }
 
@@ -1135,7 +1216,8 @@ extern "C" int mgn_train_edge_bwd(const float* e_in, const float* g_e, const flo
                   (int)n_nodes, (int)n_edges};
     const int g = train_grid(n_edges, 1);
     hipLaunchKernelGGL(train_edge_bwd_kernel, dim3(g), dim3(NT), 0, s, a);
-    launch_reduce((const float*)scratch, g, PARTIAL_E, PARTIAL_W, H, dW1, 3, db1, dgamma, dbeta, s);
+    if (launch_reduce((const float*)scratch, g, PARTIAL_E, PARTIAL_W, H, dW1, 3, db1, dgamma, dbeta, s))
+        { mgn_set_error("mgn_train_edge_bwd: the deferred-reduction list is full"); return MGN_E_CAP; }
     return check_launch("mgn_train_edge_bwd");
 }
 

@@ -131,6 +131,14 @@ class Topology:
             self.perm = torch.from_numpy(np.ascontiguousarray(perm)).to(self.device)
             self.max_in_degree = int(np.diff(rowptr).max()) if num_nodes > 0 else 0
         self._sender_view = None
+        self._min_deg = {}
+
+    def min_in_degree(self, first_rows: int = None) -> int:
+        """Smallest in-degree among the first ``first_rows`` nodes (default: all), looked up once per topology."""
+        n = self.num_nodes if first_rows is None else int(first_rows)
+        if n not in self._min_deg:
+            self._min_deg[n] = int((self.rowptr[1: n + 1] - self.rowptr[:n]).min()) if n > 0 else 0
+        return self._min_deg[n]
 
     @staticmethod
     def _resolved(device: torch.device) -> torch.device:

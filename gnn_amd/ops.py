@@ -737,7 +737,54 @@ def train_ln_fwd(v, gamma, beta, y=None, res=None, yres=None):
     _lib.check(rc, "mgn_train_ln_fwd")
 
 
-def _scratch(scratch):
+class DeferredReductions:
+    """Partial-sum space and record list for one backward pass whose weight-gradient reductions run as one launch at
+    the end (``mgn_train_defer_reductions`` / ``mgn_train_reduce_many``) instead of one small launch per call -- 88 of
+    them in a ten-block step.  Pass the object as the ``scratch`` argument of ``train_ln_bwd`` / ``train_linear_bwd`` /
+    ``train_edge_bwd`` inside ``with deferred:``; the gradients those calls name are defined after :meth:`flush`.
+    Every call gets partial space of its own from a pool that grows on demand and is kept from step to step (so a
+    captured step replays on fixed addresses)."""
+
+    CAPACITY = 512
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.recs = (_lib.MgnReduceRec * self.CAPACITY)()
+        self.count = C.c_int32(0)
+        self.chunks, self.chunk, self.offset = [], -1, 0
+
+    def __enter__(self):
+        self.count.value, self.chunk, self.offset = 0, (0 if self.chunks else -1), 0
+        _lib.check(_lib.lib().mgn_train_defer_reductions(self.recs, self.CAPACITY, C.byref(self.count)), "mgn_train_defer_reductions")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.lib().mgn_train_defer_reductions(None, 0, None)
+        return False
+
+    def take(self, kind: int, rows: int) -> int:
+        """Device address of the partial space for the next call of ``kind`` (0 linear_bwd, 1 ln_bwd, 2 edge_bwd)."""
+        need = int(_lib.lib().mgn_train_partial_bytes(kind, rows))
+        if need < 0:
+            raise RuntimeError("mgn_train_partial_bytes: bad arguments")
+        need = (need + 255) & ~255
+        while self.chunk < 0 or self.offset + need > self.chunks[self.chunk].numel():
+            self.chunk, self.offset = self.chunk + 1, 0
+            if self.chunk == len(self.chunks):
+                self.chunks.append(torch.empty(max(need, 256 << 20), dtype=torch.uint8, device=self.device))
+        ptr = self.chunks[self.chunk].data_ptr() + self.offset
+        self.offset += need
+        return ptr
+
+    def flush(self):
+        """Runs all recorded reductions (one launch per 48 records) on the current stream."""
+        n, self.count.value = self.count.value, 0
+        _lib.check(_lib.lib().mgn_train_reduce_many(self.recs, n, _stream()), "mgn_train_reduce_many")
+
+
+def _scratch(scratch, kind=0, rows=0):
+    if isinstance(scratch, DeferredReductions):
+        return scratch.take(kind, rows)
     p = _dev(scratch, torch.uint8, None, "scratch")
     if scratch.numel() < train_scratch_bytes():
         raise RuntimeError("training scratch buffer is smaller than mgn_train_scratch_bytes()")
@@ -755,7 +802,7 @@ def train_ln_bwd(v, gamma, gpre, dgamma, dbeta, scratch, g=None, gg=None, idx=No
                                      _opt(idx, torch.int32, (rows,), "idx"), _rows128(v, "v"),
                                      _dev(gamma, torch.float32, (H,), "gamma"), int(bool(relu_mask)),
                                      _rows128(gpre, "gpre", rows), _dev(dgamma, torch.float32, (H,), "dgamma"),
-                                     _dev(dbeta, torch.float32, (H,), "dbeta"), _scratch(scratch), rows, _stream())
+                                     _dev(dbeta, torch.float32, (H,), "dbeta"), _scratch(scratch, 1, rows), rows, _stream())
     _lib.check(rc, "mgn_train_ln_bwd")
 
 
@@ -780,7 +827,7 @@ def train_linear_bwd(g, scratch, a=None, w=None, koff=0, mask=None, res=None, ga
         C.c_void_p(0) if w is None else _wblock(w, koff, "W"), 0 if w is None else w.shape[1], koff,
         _opt(mask, torch.float32, (rows, H), "mask"), _opt(res, torch.float32, (rows, H), "res"),
         _opt(ga, torch.float32, (rows, H), "GA"), dw_ptr, lddw, _opt(db, torch.float32, (H,), "db"),
-        _scratch(scratch), rows, _stream())
+        0 if dw is None and isinstance(scratch, DeferredReductions) else _scratch(scratch, 0, rows), rows, _stream())
     _lib.check(rc, "mgn_train_linear_bwd")
 
 
@@ -797,7 +844,7 @@ def train_edge_bwd(e_in, g_e, g_aggr, ps, pr, sender, recv, rowptr, w0, w1, b1, 
         _dev(w1, torch.float32, (H, H), "w1"), _dev(b1, torch.float32, (H,), "b1"), _dev(ln_w, torch.float32, (H,), "ln_w"),
         _rows128(g1, "g1", e), _rows128(dpr, "dpr"), _dev(dw1, torch.float32, (H, H), "dW1"),
         _dev(db1, torch.float32, (H,), "db1"), _dev(dgamma, torch.float32, (H,), "dgamma"),
-        _dev(dbeta, torch.float32, (H,), "dbeta"), _scratch(scratch), n, e, _stream())
+        _dev(dbeta, torch.float32, (H,), "dbeta"), _scratch(scratch, 2, e), n, e, _stream())
     _lib.check(rc, "mgn_train_edge_bwd")
 
 

@@ -38,6 +38,19 @@ class _Scratch:
         return buf
 
 
+class _Deferred:
+    """One :class:`ops.DeferredReductions` per device and host thread, kept from step to step."""
+    _by_dev: Dict[tuple, "ops.DeferredReductions"] = {}
+
+    @classmethod
+    def get(cls, dev):
+        key = (str(dev), threading.get_ident())
+        d = cls._by_dev.get(key)
+        if d is None:
+            d = cls._by_dev[key] = ops.DeferredReductions(dev)
+        return d
+
+
 def _pad_cols(w: torch.Tensor) -> torch.Tensor:
     """[128, F] -> [128, 128] with zero columns (first Linear of an encoder)."""
     out = torch.zeros(H, H, dtype=torch.float32, device=w.device)
@@ -143,7 +156,8 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
                 att = (a_proj, alpha, wts)
             if fused:
                 # whole edge update in one kernel; hidden activations are recomputed in the backward
-                aggr = torch.zeros(n, H, dtype=torch.float32, device=dev)     # receivers without in-edges stay 0
+                # the edge kernel writes the sum of every receiver that has in-edges; the others must read as zero
+                aggr = _empty(n, dev) if topo.min_in_degree(n) > 0 else torch.zeros(n, H, dtype=torch.float32, device=dev)
                 # the edge latents after the last block are unused, except by the backward of the message weights
                 e_next = None if last and att is None else _empty(e, dev)
                 with ops.timed("mp_edge"):
@@ -227,13 +241,24 @@ def forward_saving(model, graph, target_norm: torch.Tensor, fused=None, keep_hid
 
 
 def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """Gradients of ``sum_c grad3[c] * loss3[c]`` for every parameter, keyed like ``named_parameters``."""
+    """Gradients of ``sum_c grad3[c] * loss3[c]`` for every parameter, keyed like ``named_parameters``.
+    The per-workgroup partial sums of all weight gradients are reduced by one launch at the end of the pass
+    (``MGN_TRAIN_DEFER=0``: one small launch per call, the same sums bit for bit)."""
+    dev = grad3.device
+    if os.environ.get("MGN_TRAIN_DEFER", "1") == "0":
+        return _backward(model, saved, grad3, _Scratch.get(dev), None)
+    deferred = _Deferred.get(dev)
+    with deferred:
+        return _backward(model, saved, grad3, deferred, deferred.flush)
+
+
+def _backward(model, saved, grad3, scratch, flush) -> Dict[str, torch.Tensor]:
     topo, halo = saved["topo"], saved["halo"]
     dev = grad3.device
     n_loc, e, T = topo.num_nodes, topo.num_edges, model.time_dim
     n = halo.num_owned if halo is not None else n_loc
-    scratch = _Scratch.get(dev)
     grads: Dict[str, torch.Tensor] = {}
+    narrowed = []                                 # (name, padded gradient, slicer): cut to the parameter's shape once it is reduced
 
     def g_like(p):
         return torch.empty_like(p, dtype=torch.float32)
@@ -249,8 +274,9 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
     dw2p, db2p = torch.empty(H, H, dtype=torch.float32, device=dev), vec()
     gh = _empty(n, dev)
     ops.train_linear_bwd(gdec, scratch, a=saved["hd"], w=saved["w2p"], mask=saved["hd"], ga=gh, dw=dw2p, db=db2p)
-    grads["node_decoder.2.weight"] = dw2p[:n_out].contiguous()
-    grads["node_decoder.2.bias"] = db2p[:n_out].contiguous()
+    narrowed.append(("node_decoder.2.weight", dw2p, lambda t: t[:n_out].contiguous()))
+    narrowed.append(("node_decoder.2.bias", db2p, lambda t: t[:n_out].contiguous()))
+    grads["node_decoder.2.weight"] = grads["node_decoder.2.bias"] = None          # keeps the parameter order of the dict
     gx = gdec                                     # reuse: gradient wrt the node latents entering the decoder
     dw, db = g_like(dec[0].weight), vec()
     coarse, gmap = saved.get("coarse"), None
@@ -368,7 +394,9 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
         grads[name + ".2.weight"], grads[name + ".2.bias"] = dw, db
         dwp, db = torch.empty(H, H, dtype=torch.float32, device=dev), vec()
         ops.train_linear_bwd(g_b, scratch, a=inp, dw=dwp, db=db)
-        grads[name + ".0.weight"] = dwp[:, : seq[0].weight.shape[1]].contiguous()
+        width = seq[0].weight.shape[1]
+        narrowed.append((name + ".0.weight", dwp, lambda t: t[:, :width].contiguous()))
+        grads[name + ".0.weight"] = None
         grads[name + ".0.bias"] = db
 
     encoder_bwd(model.node_encoder, "node_encoder", saved["enc_n"], gx, g2n, g1n)
@@ -383,6 +411,10 @@ def backward(model, saved, grad3: torch.Tensor) -> Dict[str, torch.Tensor]:
         if g2ec is None:
             g2ec = _empty(ec, dev)
         encoder_bwd(model.coarse_edge_encoder, "coarse_edge_encoder", coarse["enc_c"], gec, g2ec, g1ec)
+    if flush is not None:
+        flush()                                   # every weight gradient of the step in one reduction launch
+    for name, padded, cut in narrowed:
+        grads[name] = cut(padded)
     if halo is not None:
         # each rank holds the sums over its own rows: one all-reduce over all 136 tensors (4.84 MB)
         flat = torch.cat([g.reshape(-1) for g in grads.values()])

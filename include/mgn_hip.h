@@ -308,6 +308,25 @@ int mgn_scatter_rows(const float* src, const int64_t* idx, float* dst, int64_t r
  * ------------------------------------------------------------------------------------- */
 int64_t mgn_train_scratch_bytes(void);
 
+/* One reduction launch per step instead of one per call.  mgn_train_ln_bwd, mgn_train_linear_bwd and mgn_train_edge_bwd
+ * each end with a small launch that sums their per-workgroup partials (88 of them in a ten-block step, the same sums
+ * torch's autograd forms inside its matrix products at run_train_multiscale.py:141).  While a record list is installed
+ * for the calling thread (mgn_train_defer_reductions; recs == NULL removes it), these entry points append a record to
+ * the list (*count grows) instead of launching; the gradients they name (dW, db, dgamma, dbeta) are then undefined until
+ * mgn_train_reduce_many has run over the records.  Every deferred call needs partial space of its own, alive until then:
+ * mgn_train_partial_bytes(kind, rows) bytes at `scratch` (kind 0: linear_bwd, 1: ln_bwd, 2: edge_bwd with rows = edges).
+ * A call that finds the list full still reduces at once and returns an error.  Same arithmetic, same order: the
+ * results are those of the per-call launches bit for bit.  The list lives in host memory; nothing here allocates. */
+typedef struct MgnReduceRec {
+    const float* partial;        /* per-workgroup partials */
+    float* out;                  /* matrix destination (mcount floats, row stride ld) or NULL */
+    float* vec[3];               /* up to three 128-float vector destinations */
+    int32_t nblocks, stride, mcount, ld, nvec, reserved;
+} MgnReduceRec;
+int64_t mgn_train_partial_bytes(int32_t kind, int64_t rows);
+int mgn_train_defer_reductions(MgnReduceRec* recs /*host*/, int32_t capacity, int32_t* count /*host, in/out*/);
+int mgn_train_reduce_many(const MgnReduceRec* recs /*host*/, int32_t n, void* stream);
+
 /* nn.Linear forward (core/meshgraphnet.py:36-43 as used at :95-96, :116-117):
  * out[r,f] = act( sum_k A[r,k] W[f,koff_a+k] (+ sum_k B[r,k] W[f,koff_b+k]) (+ bias[f])
  *                 (+ P[idxP[r],f] + Q[idxQ[r],f]) ),  act = ReLU if relu else identity.

@@ -321,6 +321,58 @@ def test_fused_edge_backward_matches_unfused():
     assert worst[0] < 2e-6, worst
 
 
+@pytest.mark.parametrize("options", [False, True], ids=["default", "attention+multiscale"])
+def test_one_reduction_launch_per_step_changes_nothing(options, monkeypatch):
+    """All weight-gradient partial sums of a backward pass reduced by one launch at its end (the default) against one
+    small launch per call (MGN_TRAIN_DEFER=0): every gradient bit for bit, also on the second step (the partial-sum
+    pool is reused), and through the C entry points directly with a record list that is too short."""
+    import ctypes as C
+    from gnn_amd import _lib, ops, training
+    if options:
+        from test_gpu_options import build
+        cfg = O.OracleConfig(process_steps=2, attention=True, sample_ratio=0.4, coarse_process_steps=2)
+    else:
+        build = build_model
+        cfg = O.OracleConfig(process_steps=3)
+    sd = O.init_state_dict(cfg, 9)
+    g = O.synthetic_graph(37, 23, seed=4)
+    n = g["mesh_pos"].shape[0]
+    g["target"] = torch.cat([g["world_pos"], g["phi"]], -1).unsqueeze(0) + 1e-2 * torch.randn(1, n, 3, generator=torch.Generator().manual_seed(3))
+    gg = graph_to(g, DEV)
+    out = {}
+    for defer in ("1", "0"):
+        monkeypatch.setenv("MGN_TRAIN_DEFER", defer)
+        model = build(cfg, sd)
+        model.coarse_start = 3
+        steps = []
+        for _ in range(2):
+            tgt = model._normalized_target(gg)
+            loss3, saved = training.forward_saving(model, gg, tgt)
+            steps.append({k: v.clone() for k, v in training.backward(model, saved, torch.ones(3, device=DEV)).items()})
+        out[defer] = steps
+    for a, b in zip(out["1"], out["0"]):
+        assert list(a.keys()) == list(b.keys())
+        for k in a:
+            assert a[k].shape == b[k].shape and torch.equal(a[k], b[k]), k
+    # a list with room for one record: the second call reduces at once and reports the full list
+    d = ops.DeferredReductions(DEV)
+    d.recs = (_lib.MgnReduceRec * 1)()
+    gen = torch.Generator().manual_seed(1)
+    G, A = torch.randn(500, 128, generator=gen).to(DEV), torch.randn(500, 128, generator=gen).to(DEV)
+    dw1, dw2, dw_ref = (torch.empty(128, 128, device=DEV) for _ in range(3))
+    ops.train_linear_bwd(G, torch.empty(ops.train_scratch_bytes(), dtype=torch.uint8, device=DEV), a=A, dw=dw_ref)
+    _lib.check(_lib.lib().mgn_train_defer_reductions(d.recs, 1, C.byref(d.count)), "defer")
+    try:
+        ops.train_linear_bwd(G, d, a=A, dw=dw1)
+        with pytest.raises(RuntimeError, match="list is full"):
+            ops.train_linear_bwd(G, d, a=A, dw=dw2)
+    finally:
+        _lib.lib().mgn_train_defer_reductions(None, 0, None)
+    assert d.count.value == 1 and torch.equal(dw2, dw_ref)             # reduced at once all the same
+    d.flush()
+    assert torch.equal(dw1, dw_ref)
+
+
 def test_full_size_training_step_properties():
     """The training configuration at its full size (500 x 500 nodes, 10 message-passing steps), where
     the oracle's autograd is out of reach, through properties that do not depend on size:
