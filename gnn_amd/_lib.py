@@ -59,6 +59,9 @@ SIGNATURES = {
     "mgn_mp_node_project": (C.c_int, [_P, _P, _P, _MLP, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_node_features": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P]),
     "mgn_edge_features": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgn_node_features_sums": (C.c_int, [_P, _P, _P, _P, _I32, _P, _P, _P, _I64, _P, _P]),
+    "mgn_edge_features_sums": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "mgn_norm_fold": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _I64, _F, _P, _P]),
     "mgn_feature_sums_scratch_bytes": (_I64, [_I64, _I32]),
     "mgn_feature_sums": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
     "mgn_feature_sums_static": (C.c_int, [_P, _I64, _I32, _P, _P]),
@@ -69,6 +72,7 @@ SIGNATURES = {
     "mgn_inject_noise": (C.c_int, [_P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _I64, _P]),
     "mgn_encode": (C.c_int, [_P, _I32, _P, _MLP, _P, _I64, _P]),
     "mgn_decode": (C.c_int, [_P, _MLP, _I32, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgn_decode_step": (C.c_int, [_P, _MLP, _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgn_gather_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
     "mgn_scatter_rows": (C.c_int, [_P, _P, _P, _I64, _I32, _P]),
     "mgn_train_scratch_bytes": (_I64, []),

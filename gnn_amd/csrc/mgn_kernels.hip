@@ -1026,6 +1026,7 @@ struct DecArgs {
     const float* x; const float* w0; const float* b0; const float* w1; const float* b1;
     float* delta_norm; const float* out_mean_std; const float* world_pos; const float* phi; const float* node_type;
     float* pred; int n_nodes; int time_dim; int out_dim;
+    float* next_world; float* next_phi;      // or null: the last predicted step also written as the next state (may alias world_pos / phi)
 };
 
 template <bool HALF>
@@ -1112,6 +1113,9 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
             else o = wave_gemm<16>(Hs, H / 4, 0, wb, j, h, o);
             if (j < nvalid) {
                 const int n = base + j;
+                // the row's current state, read by both lanes of the row before either writes the next state over it
+                float cur3[3] = {0.f, 0.f, 0.f};
+                if (a.pred) { cur3[0] = a.world_pos[(size_t)n * 2]; cur3[1] = a.world_pos[(size_t)n * 2 + 1]; cur3[2] = a.phi[n]; }
 #pragma unroll
                 for (int reg = 0; reg < 16; ++reg) {
                     const int oi = (reg & 3) + 8 * (reg >> 2) + 4 * h;     // decoder output index
@@ -1122,8 +1126,11 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
                         if (a.pred) {
                             float d = os[oi] * dn + om[oi];
                             if (a.node_type[(size_t)n * 5 + k + 1] == 1.0f) d = 0.f;
-                            const float cur = (k < 2) ? a.world_pos[(size_t)n * 2 + k] : a.phi[n];
-                            a.pred[((size_t)tt * a.n_nodes + n) * 3 + k] = cur + d;
+                            const float nxt = (k == 0 ? cur3[0] : k == 1 ? cur3[1] : cur3[2]) + d;
+                            a.pred[((size_t)tt * a.n_nodes + n) * 3 + k] = nxt;
+                            if (a.next_world && tt == a.time_dim - 1) {
+                                if (k < 2) a.next_world[(size_t)n * 2 + k] = nxt; else a.next_phi[n] = nxt;
+                            }
                         }
                     }
                 }
@@ -1135,34 +1142,41 @@ __global__ __launch_bounds__(NT, 2) void decode_kernel(DecArgs a) {
 }
 
 // ======================================================================== features / normaliser
+__device__ inline void node_feature_row(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
+                                        const float* __restrict__ phi, const float* __restrict__ swell, int n_swell,
+                                        const float* __restrict__ node_type, const float* __restrict__ mat_param, int n,
+                                        float* f) {
+    f[0] = world_pos[2 * n] - mesh_pos[2 * n];
+    f[1] = world_pos[2 * n + 1] - mesh_pos[2 * n + 1];
+    f[2] = phi[n];
+    for (int k = 0; k < n_swell; ++k) f[3 + k] = swell[(size_t)n * n_swell + k];
+    for (int k = 0; k < 5; ++k) f[3 + n_swell + k] = node_type[(size_t)n * 5 + k];
+    if (mat_param) { f[8 + n_swell] = mat_param[0]; f[9 + n_swell] = mat_param[1]; }
+}
+
 __global__ void node_features_kernel(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
                                      const float* __restrict__ phi, const float* __restrict__ swell, int n_swell,
                                      const float* __restrict__ node_type, const float* __restrict__ mat_param,
                                      float* __restrict__ feat, int n_nodes) {
     const int F = 3 + n_swell + 5 + (mat_param ? 2 : 0);
-    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += gridDim.x * blockDim.x) {
-        float* f = feat + (size_t)n * F;
-        f[0] = world_pos[2 * n] - mesh_pos[2 * n];
-        f[1] = world_pos[2 * n + 1] - mesh_pos[2 * n + 1];
-        f[2] = phi[n];
-        for (int k = 0; k < n_swell; ++k) f[3 + k] = swell[(size_t)n * n_swell + k];
-        for (int k = 0; k < 5; ++k) f[3 + n_swell + k] = node_type[(size_t)n * 5 + k];
-        if (mat_param) { f[8 + n_swell] = mat_param[0]; f[9 + n_swell] = mat_param[1]; }
-    }
+    for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < n_nodes; n += gridDim.x * blockDim.x)
+        node_feature_row(world_pos, mesh_pos, phi, swell, n_swell, node_type, mat_param, n, feat + (size_t)n * F);
+}
+
+__device__ inline void edge_feature_row(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
+                                        const float* __restrict__ phi, int s, int r, float* f) {
+    const float mx = mesh_pos[2 * s] - mesh_pos[2 * r], my = mesh_pos[2 * s + 1] - mesh_pos[2 * r + 1];
+    const float wx = world_pos[2 * s] - world_pos[2 * r], wy = world_pos[2 * s + 1] - world_pos[2 * r + 1];
+    f[0] = mx; f[1] = my; f[2] = sqrtf(mx * mx + my * my);
+    f[3] = wx; f[4] = wy; f[5] = sqrtf(wx * wx + wy * wy);
+    f[6] = phi[s] - phi[r];
 }
 
 __global__ void edge_features_kernel(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
                                      const float* __restrict__ phi, const int* __restrict__ sender,
                                      const int* __restrict__ recv, float* __restrict__ feat, int n_edges) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += gridDim.x * blockDim.x) {
-        const int s = sender[e], r = recv[e];
-        const float mx = mesh_pos[2 * s] - mesh_pos[2 * r], my = mesh_pos[2 * s + 1] - mesh_pos[2 * r + 1];
-        const float wx = world_pos[2 * s] - world_pos[2 * r], wy = world_pos[2 * s + 1] - world_pos[2 * r + 1];
-        float* f = feat + (size_t)e * 7;
-        f[0] = mx; f[1] = my; f[2] = sqrtf(mx * mx + my * my);
-        f[3] = wx; f[4] = wy; f[5] = sqrtf(wx * wx + wy * wy);
-        f[6] = phi[s] - phi[r];
-    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_edges; e += gridDim.x * blockDim.x)
+        edge_feature_row(world_pos, mesh_pos, phi, sender[e], recv[e], feat + (size_t)e * 7);
 }
 
 // ======================================================================== attention weights of the messages
@@ -1217,20 +1231,10 @@ __global__ __launch_bounds__(NT) void pack_weights_kernel(PackTable tab, u32x4* 
 
 constexpr int SUM_BLOCKS_MAX = 1024;
 
-__global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* __restrict__ feat, long long rows,
-                                                                  int F, double* __restrict__ partial) {
+// One block's float64 column sums [sum | sum of squares] from the per-thread sums: fixed order -- butterfly within each
+// wave, then the four wave sums in wave order (one barrier in all).
+__device__ inline void block_partial_sums(const double* s, const double* q, int F, double* __restrict__ partial) {
     __shared__ double sh[NT / 64][2 * MGN_MAX_FEAT];
-    const long long per = (rows + gridDim.x - 1) / gridDim.x;
-    const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
-    double s[MGN_MAX_FEAT], q[MGN_MAX_FEAT];
-#pragma unroll
-    for (int k = 0; k < MGN_MAX_FEAT; ++k) { s[k] = 0.0; q[k] = 0.0; }
-    for (long long r = r0 + threadIdx.x; r < r1; r += NT) {
-#pragma unroll
-        for (int k = 0; k < MGN_MAX_FEAT; ++k)
-            if (k < F) { const double v = feat[r * F + k]; s[k] += v; q[k] += v * v; }
-    }
-    // fixed order: butterfly within each wave, then the four wave sums in wave order (one barrier in all)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < MGN_MAX_FEAT; ++k) {
@@ -1248,6 +1252,63 @@ __global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* _
         for (int v = 1; v < NT / 64; ++v) tot += sh[v][k];
         partial[(size_t)blockIdx.x * 2 * MGN_MAX_FEAT + k] = tot;
     }
+}
+
+__global__ __launch_bounds__(NT) void feature_sums_partial_kernel(const float* __restrict__ feat, long long rows,
+                                                                  int F, double* __restrict__ partial) {
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    double s[MGN_MAX_FEAT], q[MGN_MAX_FEAT];
+#pragma unroll
+    for (int k = 0; k < MGN_MAX_FEAT; ++k) { s[k] = 0.0; q[k] = 0.0; }
+    for (long long r = r0 + threadIdx.x; r < r1; r += NT) {
+#pragma unroll
+        for (int k = 0; k < MGN_MAX_FEAT; ++k)
+            if (k < F) { const double v = feat[r * F + k]; s[k] += v; q[k] += v * v; }
+    }
+    block_partial_sums(s, q, F, partial);
+}
+
+// Feature rows and their per-block column sums in one pass: the rows of feature_sums_partial_kernel's block, visited in
+// its order, summed from the values just written -- the partials are those of a separate mgn_feature_sums pass bit for bit.
+__global__ __launch_bounds__(NT) void node_features_sums_kernel(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
+                                                                const float* __restrict__ phi, const float* __restrict__ swell,
+                                                                int n_swell, const float* __restrict__ node_type,
+                                                                const float* __restrict__ mat_param, float* __restrict__ feat,
+                                                                long long rows, double* __restrict__ partial) {
+    const int F = 3 + n_swell + 5 + (mat_param ? 2 : 0);
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    double s[MGN_MAX_FEAT], q[MGN_MAX_FEAT];
+#pragma unroll
+    for (int k = 0; k < MGN_MAX_FEAT; ++k) { s[k] = 0.0; q[k] = 0.0; }
+    for (long long r = r0 + threadIdx.x; r < r1; r += NT) {
+        float f[MGN_MAX_FEAT];
+        node_feature_row(world_pos, mesh_pos, phi, swell, n_swell, node_type, mat_param, (int)r, f);
+#pragma unroll
+        for (int k = 0; k < MGN_MAX_FEAT; ++k)
+            if (k < F) { feat[r * F + k] = f[k]; const double v = f[k]; s[k] += v; q[k] += v * v; }
+    }
+    block_partial_sums(s, q, F, partial);
+}
+
+__global__ __launch_bounds__(NT) void edge_features_sums_kernel(const float* __restrict__ world_pos, const float* __restrict__ mesh_pos,
+                                                                const float* __restrict__ phi, const int* __restrict__ sender,
+                                                                const int* __restrict__ recv, float* __restrict__ feat,
+                                                                long long rows, double* __restrict__ partial) {
+    constexpr int F = 7;
+    const long long per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r0 = (long long)blockIdx.x * per, r1 = min(rows, r0 + per);
+    double s[MGN_MAX_FEAT], q[MGN_MAX_FEAT];
+#pragma unroll
+    for (int k = 0; k < MGN_MAX_FEAT; ++k) { s[k] = 0.0; q[k] = 0.0; }
+    for (long long r = r0 + threadIdx.x; r < r1; r += NT) {
+        float f[F];
+        edge_feature_row(world_pos, mesh_pos, phi, sender[r], recv[r], f);
+#pragma unroll
+        for (int k = 0; k < F; ++k) { feat[r * F + k] = f[k]; const double v = f[k]; s[k] += v; q[k] += v * v; }
+    }
+    block_partial_sums(s, q, F, partial);
 }
 
 // 256 threads: thread (c = t / 32, col = t % 32) adds the partials of blocks c, c+8, c+16, ... of
@@ -1274,6 +1335,49 @@ __global__ __launch_bounds__(NT) void feature_sums_final_kernel(const double* __
         for (int q = 0; q < 8; ++q) tot += sh[q][pc];
         sums[k] = tot;
     }
+}
+
+// feature_sums_final_kernel and the statistics update in one launch: the block partials are added in that kernel's order
+// (eight chunk sums, then the chunks), the totals stay in LDS, and threads k < F fold them into the accumulators and
+// write [mean | std] exactly as norm_update_kernel / norm_update_counted_kernel do (count: device word or NULL).
+__global__ __launch_bounds__(NT) void norm_fold_kernel(const double* __restrict__ partial, int nblocks, int F, float* acc_sum,
+                                                       float* acc_sumsq, long long* count, long long host_count,
+                                                       long long add, float eps, float* mean_std) {
+    __shared__ double sh[8][2 * MGN_MAX_FEAT];
+    __shared__ double fin[2 * MGN_MAX_FEAT];
+    const int col = threadIdx.x & (2 * MGN_MAX_FEAT - 1), c = threadIdx.x / (2 * MGN_MAX_FEAT);
+    double acc = 0.0;
+    int b = c;
+    for (; b + 56 < nblocks; b += 64) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + 8 * u) * 2 * MGN_MAX_FEAT + col];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < nblocks; b += 8) acc += partial[(size_t)b * 2 * MGN_MAX_FEAT + col];
+    sh[c][col] = acc;
+    __syncthreads();
+    if (threadIdx.x < 2 * F) {
+        const int k = threadIdx.x, pc = (k < F) ? k : MGN_MAX_FEAT + (k - F);
+        double tot = 0.0;
+        for (int q = 0; q < 8; ++q) tot += sh[q][pc];
+        fin[k] = tot;
+    }
+    const long long cnt = count ? *count + add : host_count;     // host_count already includes the rows of this call
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < F) {
+        const float safe_count = (float)(cnt > 1 ? cnt : 1);
+        float s = acc_sum[k], q = acc_sumsq[k];
+        s += (float)fin[k]; q += (float)fin[F + k];
+        acc_sum[k] = s; acc_sumsq[k] = q;
+        const float mean = s / safe_count;
+        const float var = fmaxf(q / safe_count - mean * mean, 0.f);
+        mean_std[k] = mean;
+        mean_std[F + k] = sqrtf(var + eps);
+    }
+    if (k == 0 && count && add) *count = cnt;
 }
 
 __global__ void norm_update_kernel(float* acc_sum, float* acc_sumsq, const double* sums, int F, float safe_count,
@@ -1554,6 +1658,36 @@ static int sum_blocks(int64_t rows) {
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, SUM_BLOCKS_MAX));
 }
 
+extern "C" int mgn_node_features_sums(const float* world_pos, const float* mesh_pos, const float* phi,
+                                      const float* swelling_phi, int32_t n_swell, const float* node_type,
+                                      const float* mat_param, float* feat, int64_t n_nodes, void* scratch, void* stream) {
+    MGN_REQUIRE(n_nodes > 0 && n_nodes < (1ll << 31) && n_swell >= 0 && scratch, "mgn_node_features_sums");
+    MGN_REQUIRE(3 + n_swell + 5 + (mat_param ? 2 : 0) <= MGN_MAX_FEAT, "mgn_node_features_sums");
+    MGN_REQUIRE(world_pos && mesh_pos && phi && node_type && feat && (n_swell == 0 || swelling_phi), "mgn_node_features_sums");
+    hipLaunchKernelGGL(node_features_sums_kernel, dim3(sum_blocks(n_nodes)), dim3(NT), 0, (hipStream_t)stream, world_pos,
+                       mesh_pos, phi, swelling_phi, n_swell, node_type, mat_param, feat, (long long)n_nodes, (double*)scratch);
+    return check_launch("mgn_node_features_sums");
+}
+
+extern "C" int mgn_edge_features_sums(const float* world_pos, const float* mesh_pos, const float* phi,
+                                      const int32_t* csr_sender, const int32_t* csr_recv, float* feat, int64_t n_edges,
+                                      void* scratch, void* stream) {
+    MGN_REQUIRE(n_edges > 0 && n_edges < (1ll << 31) && scratch, "mgn_edge_features_sums");
+    MGN_REQUIRE(world_pos && mesh_pos && phi && csr_sender && csr_recv && feat, "mgn_edge_features_sums");
+    hipLaunchKernelGGL(edge_features_sums_kernel, dim3(sum_blocks(n_edges)), dim3(NT), 0, (hipStream_t)stream, world_pos,
+                       mesh_pos, phi, csr_sender, csr_recv, feat, (long long)n_edges, (double*)scratch);
+    return check_launch("mgn_edge_features_sums");
+}
+
+extern "C" int mgn_norm_fold(const void* scratch, int64_t rows, int32_t n_feat, float* acc_sum, float* acc_sumsq,
+                             int64_t* count_dev, int64_t count, float eps, float* mean_std, void* stream) {
+    MGN_REQUIRE(scratch && rows > 0 && n_feat > 0 && n_feat <= MGN_MAX_FEAT && acc_sum && acc_sumsq && mean_std && count >= 0,
+                "mgn_norm_fold");
+    hipLaunchKernelGGL(norm_fold_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, (const double*)scratch, sum_blocks(rows),
+                       (int)n_feat, acc_sum, acc_sumsq, (long long*)count_dev, (long long)count, (long long)rows, eps, mean_std);
+    return check_launch("mgn_norm_fold");
+}
+
 extern "C" int64_t mgn_feature_sums_scratch_bytes(int64_t rows, int32_t n_feat) {
     (void)n_feat;
     return (int64_t)sum_blocks(rows < 0 ? 0 : rows) * 2 * MGN_MAX_FEAT * (int64_t)sizeof(double);
@@ -1690,11 +1824,26 @@ extern "C" int mgn_decode(const float* x, const mgn_mlp* dec, int32_t time_dim, 
     MGN_REQUIRE(x && mlp_ok(dec, false) && (delta_norm || pred), "mgn_decode");
     MGN_REQUIRE(!pred || (out_dim == 3 && out_mean_std && world_pos && phi && node_type), "mgn_decode");
     DecArgs a{x, dec->w0, dec->b0, dec->w1, dec->b1, delta_norm, out_mean_std, world_pos, phi, node_type,
-              pred, (int)n_nodes, (int)time_dim, (int)out_dim};
+              pred, (int)n_nodes, (int)time_dim, (int)out_dim, nullptr, nullptr};
     const int g = grid_for((n_nodes + TM - 1) / TM, 2);
     if (matmul_mode() == 2) hipLaunchKernelGGL((decode_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((decode_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     return check_launch("mgn_decode");
+}
+
+extern "C" int mgn_decode_step(const float* x, const mgn_mlp* dec, int32_t time_dim, const float* out_mean_std,
+                               const float* world_pos, const float* phi, const float* node_type, float* pred,
+                               float* next_world, float* next_phi, int64_t n_nodes, void* stream) {
+    MGN_REQUIRE(n_nodes >= 0 && n_nodes < (1ll << 31) && time_dim > 0 && time_dim * 3 <= MGN_MAX_DEC_OUT, "mgn_decode_step");
+    if (n_nodes == 0) return 0;
+    MGN_REQUIRE(x && mlp_ok(dec, false) && pred && out_mean_std && world_pos && phi && node_type && next_world && next_phi,
+                "mgn_decode_step");
+    DecArgs a{x, dec->w0, dec->b0, dec->w1, dec->b1, nullptr, out_mean_std, world_pos, phi, node_type,
+              pred, (int)n_nodes, (int)time_dim, 3, next_world, next_phi};
+    const int g = grid_for((n_nodes + TM - 1) / TM, 2);
+    if (matmul_mode() == 2) hipLaunchKernelGGL((decode_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((decode_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
+    return check_launch("mgn_decode_step");
 }
 
 extern "C" int mgn_decode_cat(const float* x, const float* x2, const mgn_mlp* dec, int32_t time_dim, int32_t out_dim,
@@ -1711,7 +1860,7 @@ extern "C" int mgn_decode_cat(const float* x, const float* x2, const mgn_mlp* de
                                         hidden_ws, n_nodes, stream);
     if (rc) return rc;
     DecArgs a{hidden_ws, nullptr, nullptr, dec->w1, dec->b1, delta_norm, out_mean_std, world_pos, phi, node_type,
-              pred, (int)n_nodes, (int)time_dim, (int)out_dim};
+              pred, (int)n_nodes, (int)time_dim, (int)out_dim, nullptr, nullptr};
     const int g = grid_for((n_nodes + TM - 1) / TM, 2);
     if (matmul_mode() == 2) hipLaunchKernelGGL((decode_kernel<true>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((decode_kernel<false>), dim3(g), dim3(NT), 0, (hipStream_t)stream, a);

@@ -399,12 +399,16 @@ class EncodeProcessDecodeMultiScale(nn.Module):
                 raise RuntimeError(f"partitioned run: world_pos / phi must hold at least the {n_own} owned rows")
             world, phi = halo.exchange_state(world, phi)      # [owned | halo] buffers of the plan, halo rows refreshed
         mat = self._f32(graph["mat_param"]) if self.with_mat_params else None
+        nn_, en_ = self.node_features_normalizer, self.edge_features_normalizer
+        # on one GPU a live normaliser's column sums are formed by the feature kernel itself and folded by one more launch
+        pn = nn_.partials_for(n_own) if halo is None and nn_.accumulating() and n_own > 0 else None
+        pe = en_.partials_for(e) if halo is None and en_.accumulating() and e > 0 else None
         ops.node_features(world[:n_own], mesh[:n_own], phi[:n_own], self._f32(graph["swelling_phi"])[:n_own],
-                          self._f32(graph["node_type"])[:n_own], mat, ws.node_feat[:n_own])
-        ops.edge_features(world, mesh, phi, topo.sender, topo.recv, ws.edge_feat)
+                          self._f32(graph["node_type"])[:n_own], mat, ws.node_feat[:n_own], partials=pn)
+        ops.edge_features(world, mesh, phi, topo.sender, topo.recv, ws.edge_feat, partials=pe)
         if halo is None:
-            ms_n = self.node_features_normalizer.stats_for(ws.node_feat, True)
-            ms_e = self.edge_features_normalizer.stats_for(ws.edge_feat, True)
+            ms_n = nn_.fold_partials(n_own) if pn is not None else nn_.stats_for(ws.node_feat, True)
+            ms_e = en_.fold_partials(e) if pe is not None else en_.stats_for(ws.edge_feat, True)
         else:                                     # partial sums of both normalisers in one all-reduce
             ms_n, ms_e = halo.feature_stats(self.node_features_normalizer, ws.node_feat[:n_own],
                                             self.edge_features_normalizer, ws.edge_feat)
@@ -463,9 +467,13 @@ class EncodeProcessDecodeMultiScale(nn.Module):
         return delta
 
     @_on_graph_device
-    def predict(self, graph, check_range: bool = True):
+    def predict(self, graph, check_range: bool = True, feedback: bool = False):
         """Next state(s) [time_dim, N, 3]: decode, de-normalise, zero the deltas of
         Dirichlet nodes, add to the current state (core/meshgraphnet.py:305-317).
+
+        ``feedback``: the decoder launch also writes the last predicted step into ``graph["world_pos"]`` /
+        ``graph["phi"]`` themselves (float32, contiguous device tensors) -- the state feedback of the rollout loop
+        (core/rollout.py:29-32) without separate copies.  Plain model on one GPU only.
 
         ``check_range``: read the range flag of the default matrix path after the launches (one small
         device-to-host copy, which waits for the step) and raise if an operand left the fp16 range; loops
@@ -479,8 +487,15 @@ class EncodeProcessDecodeMultiScale(nn.Module):
             n = halo.num_owned if halo is not None else topo.num_nodes
             ms_o = self.output_normalizer.stats_for(None, accumulate=False)
             pred = torch.empty(self.time_dim, n, 3, dtype=torch.float32, device=ws.x.device)
-            self._decode(ws, n, out_mean_std=ms_o, world_pos=self._f32(graph["world_pos"])[:n],
-                         phi=self._f32(graph["phi"])[:n], node_type=self._f32(graph["node_type"])[:n], pred=pred)
+            world, phi = self._f32(graph["world_pos"])[:n], self._f32(graph["phi"])[:n]
+            kw = {}
+            if feedback:
+                if halo is not None or self.sample_ratio > 0 or world.data_ptr() != graph["world_pos"].data_ptr() \
+                        or phi.data_ptr() != graph["phi"].data_ptr():
+                    raise RuntimeError("predict(feedback=True): plain model on one GPU, state tensors float32 and contiguous")
+                kw["next_state"] = (world, phi)
+            self._decode(ws, n, out_mean_std=ms_o, world_pos=world, phi=phi, node_type=self._f32(graph["node_type"])[:n],
+                         pred=pred, **kw)
         if check_range and not torch.cuda.is_current_stream_capturing():
             ops.raise_if_out_of_range("predict")
         return pred

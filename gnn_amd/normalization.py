@@ -105,6 +105,34 @@ class Normalizer(nn.Module):
         ops.feature_sums(rows2d, sums, w["scratch"])
         return sums
 
+    def accumulating(self) -> bool:
+        return self._num_accumulations < self._max_accumulations
+
+    def partials_for(self, rows: int) -> torch.Tensor:
+        """Float64 buffer for the per-block partial sums of ``rows`` feature rows (``ops.node_features`` /
+        ``ops.edge_features`` with ``partials=``), to be folded by :meth:`fold_partials`."""
+        self._require_device()
+        w = self._work()
+        need = ops.feature_sums_scratch_bytes(rows, self._acc_sum.numel())
+        if w["scratch"] is None or w["scratch"].numel() * 8 < need:
+            w["scratch"] = torch.empty((need + 7) // 8, dtype=torch.float64, device=self._acc_sum.device)
+        return w["scratch"]
+
+    def fold_partials(self, rows: int) -> torch.Tensor:
+        """:meth:`stats_for` for rows whose partial sums are already in :meth:`partials_for`'s buffer: one launch adds
+        them, updates the statistics (core/normalization.py:30-37) and writes ``[mean | std]`` (:39-48)."""
+        w = self._work()
+        self._acc_count += int(rows)
+        self._num_accumulations += 1
+        w["fresh"] = None
+        ops.norm_fold(w["scratch"], int(rows), self._acc_sum, self._acc_sum_squared, w.get("count_dev"), self._acc_count,
+                      self._std_epsilon, w["mean_std"])
+        return w["mean_std"]
+
+    def _stats_key(self):
+        a, b = self._acc_sum, self._acc_sum_squared
+        return (id(a), id(b), a._version, b._version, a.data_ptr(), b.data_ptr(), self._acc_count, self._std_epsilon)
+
     def fold(self, sums, rows: int) -> torch.Tensor:
         """Second half of :meth:`stats_for`: folds ``sums`` (from :meth:`local_sums`, possibly reduced over
         ranks since; None = nothing to accumulate) over ``rows`` rows into the statistics
@@ -116,6 +144,15 @@ class Normalizer(nn.Module):
             added = int(rows)
             self._acc_count += added
             self._num_accumulations += 1
+            w["fresh"] = None
+        elif w.get("count_dev") is None:
+            # nothing accumulates: [mean | std] of unchanged statistics is still in the buffer (the statistics change
+            # only through the kernels launched here, through replaced tensors or through in-place torch operations)
+            key = self._stats_key()
+            hit = w.get("fresh")
+            if hit is not None and hit[0] == key:
+                return w["mean_std"]
+            w["fresh"] = (key, self._acc_sum, self._acc_sum_squared)     # the tensors stay alive: their ids cannot be reused
         if w.get("count_dev") is not None:
             ops.norm_update_counted(self._acc_sum, self._acc_sum_squared, sums, w["count_dev"], added, self._std_epsilon,
                                     w["mean_std"])

@@ -369,25 +369,50 @@ class PackedWeights:
 
 
 # --------------------------------------------------------------------------- device: features etc.
-def node_features(world_pos, mesh_pos, phi, swelling_phi, node_type, mat_param, feat):
+def _sums_scratch(partials, rows: int, n_feat: int) -> int:
+    p = _dev(partials, torch.float64, (None,), "partials")
+    if partials.numel() * 8 < feature_sums_scratch_bytes(rows, n_feat):
+        raise RuntimeError("partial-sum buffer is smaller than mgn_feature_sums_scratch_bytes()")
+    return p
+
+
+def node_features(world_pos, mesh_pos, phi, swelling_phi, node_type, mat_param, feat, partials=None):
+    """``partials`` (float64 buffer of ``feature_sums_scratch_bytes`` bytes): the same launch also forms the per-block
+    column sums of the rows for :func:`norm_fold` (``mgn_node_features_sums``)."""
     n = world_pos.shape[0]
     ns = swelling_phi.shape[1]
     f = 3 + ns + 5 + (2 if mat_param is not None else 0)
-    rc = _lib.lib().mgn_node_features(
-        _dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(mesh_pos, torch.float32, (n, 2), "mesh_pos"),
-        _dev(phi, torch.float32, (n, 1), "phi"), _dev(swelling_phi, torch.float32, (n, ns), "swelling_phi"), ns,
-        _dev(node_type, torch.float32, (n, 5), "node_type"), _opt(mat_param, torch.float32, (2,), "mat_param"),
-        _dev(feat, torch.float32, (n, f), "feat"), n, _stream())
-    _lib.check(rc, "mgn_node_features")
+    args = (_dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(mesh_pos, torch.float32, (n, 2), "mesh_pos"),
+            _dev(phi, torch.float32, (n, 1), "phi"), _dev(swelling_phi, torch.float32, (n, ns), "swelling_phi"), ns,
+            _dev(node_type, torch.float32, (n, 5), "node_type"), _opt(mat_param, torch.float32, (2,), "mat_param"),
+            _dev(feat, torch.float32, (n, f), "feat"), n)
+    if partials is not None and n > 0:
+        _lib.check(_lib.lib().mgn_node_features_sums(*args, _sums_scratch(partials, n, f), _stream()), "mgn_node_features_sums")
+    else:
+        _lib.check(_lib.lib().mgn_node_features(*args, _stream()), "mgn_node_features")
 
 
-def edge_features(world_pos, mesh_pos, phi, csr_sender, csr_recv, feat):
+def edge_features(world_pos, mesh_pos, phi, csr_sender, csr_recv, feat, partials=None):
+    """``partials``: as in :func:`node_features` (``mgn_edge_features_sums``)."""
     n, ne = world_pos.shape[0], csr_sender.shape[0]
-    rc = _lib.lib().mgn_edge_features(
-        _dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(mesh_pos, torch.float32, (n, 2), "mesh_pos"),
-        _dev(phi, torch.float32, (n, 1), "phi"), _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
-        _dev(csr_recv, torch.int32, (ne,), "csr_recv"), _dev(feat, torch.float32, (ne, 7), "feat"), ne, _stream())
-    _lib.check(rc, "mgn_edge_features")
+    args = (_dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(mesh_pos, torch.float32, (n, 2), "mesh_pos"),
+            _dev(phi, torch.float32, (n, 1), "phi"), _dev(csr_sender, torch.int32, (ne,), "csr_sender"),
+            _dev(csr_recv, torch.int32, (ne,), "csr_recv"), _dev(feat, torch.float32, (ne, 7), "feat"), ne)
+    if partials is not None and ne > 0:
+        _lib.check(_lib.lib().mgn_edge_features_sums(*args, _sums_scratch(partials, ne, 7), _stream()), "mgn_edge_features_sums")
+    else:
+        _lib.check(_lib.lib().mgn_edge_features(*args, _stream()), "mgn_edge_features")
+
+
+def norm_fold(partials, rows: int, acc_sum, acc_sumsq, count_dev, count: int, eps: float, mean_std):
+    """Adds the per-block partial sums of ``rows`` rows, folds the totals into the accumulators and writes [mean | std]
+    (``mgn_norm_fold``); ``count``: the row count after this call, or ``count_dev`` (int64 device word, advanced by
+    ``rows``) for captured launch sequences."""
+    f = acc_sum.numel()
+    rc = _lib.lib().mgn_norm_fold(_sums_scratch(partials, rows, f), rows, f, _dev(acc_sum, torch.float32, None, "acc_sum"),
+                                  _dev(acc_sumsq, torch.float32, None, "acc_sumsq"), _opt(count_dev, torch.int64, (1,), "count_dev"),
+                                  int(count), float(eps), _dev(mean_std, torch.float32, (2 * f,), "mean_std"), _stream())
+    _lib.check(rc, "mgn_norm_fold")
 
 
 def feature_sums_scratch_bytes(rows: int, n_feat: int) -> int:
@@ -467,11 +492,24 @@ def encode(feat, mean_std, mlp: MlpWeights, out):
 
 
 def decode(x, mlp: MlpWeights, time_dim: int, out_dim: int, delta_norm=None, out_mean_std=None, world_pos=None,
-           phi=None, node_type=None, pred=None):
+           phi=None, node_type=None, pred=None, next_state=None):
+    """``next_state`` = (world_pos [N,2], phi [N,1]) buffers: the last predicted step is also written there
+    (``mgn_decode_step``: the state feedback of a rollout step; the buffers may be the current state itself)."""
     n = x.shape[0]
     n_out = time_dim * out_dim
     if mlp.in_dim != H or mlp.out_dim != n_out or n_out > MAX_DEC_OUT:
         raise RuntimeError(f"decode: decoder is {mlp.in_dim} -> {mlp.out_dim}, expected {H} -> {n_out} <= {MAX_DEC_OUT}")
+    if next_state is not None:
+        if pred is None or delta_norm is not None or out_dim != 3:
+            raise RuntimeError("decode: the state feedback goes with pred (out_dim 3) and without delta_norm")
+        rc = _lib.lib().mgn_decode_step(
+            _dev(x, torch.float32, (n, H), "x"), mlp.ref(), time_dim, _dev(out_mean_std, torch.float32, (2 * n_out,), "out_mean_std"),
+            _dev(world_pos, torch.float32, (n, 2), "world_pos"), _dev(phi, torch.float32, (n, 1), "phi"),
+            _dev(node_type, torch.float32, (n, 5), "node_type"), _dev(pred, torch.float32, (time_dim, n, 3), "pred"),
+            _dev(next_state[0], torch.float32, (n, 2), "next_world"), _dev(next_state[1], torch.float32, (n, 1), "next_phi"),
+            n, _stream())
+        _lib.check(rc, "mgn_decode_step")
+        return
     rc = _lib.lib().mgn_decode(
         _dev(x, torch.float32, (n, H), "x"), mlp.ref(), time_dim, out_dim,
         _opt(delta_norm, torch.float32, (time_dim, n, out_dim), "delta_norm"),

@@ -61,11 +61,8 @@ class _StepGraph:
             nr._acc_count, nr._num_accumulations = c, k
 
     def _body(self):
-        pred = self.model.predict(self.cur, check_range=False)
-        last = pred[-1]
-        self.cur["world_pos"].copy_(last[:, :2])
-        self.cur["phi"].copy_(last[:, 2:])
-        return pred
+        # the decoder launch writes the new state over the old one (no separate copies)
+        return self.model.predict(self.cur, check_range=False, feedback=True)
 
     def _snapshot(self):
         norms = [(nr._acc_sum.clone(), nr._acc_sum_squared.clone(), nr._acc_count, nr._num_accumulations) for nr in self.norms]

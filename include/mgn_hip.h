@@ -223,6 +223,21 @@ int64_t mgn_feature_sums_scratch_bytes(int64_t rows, int32_t n_feat);
 int mgn_feature_sums(const float* feat, int64_t rows, int32_t n_feat, double* sums /*[2F]*/,
                      void* scratch, void* stream);
 
+/* The feature builders and the normaliser's accumulation in two launches instead of four (core/meshgraphnet.py:175-178
+ * with core/normalization.py:21-23, :30-48): mgn_node_features_sums / mgn_edge_features_sums write the feature rows and,
+ * in the same pass, the per-block partial sums that mgn_feature_sums' first kernel would form from them (scratch:
+ * mgn_feature_sums_scratch_bytes(rows, F) bytes); mgn_norm_fold adds the partials of `rows` rows in mgn_feature_sums'
+ * order, folds the totals into the accumulators and writes mean_std = [mean | std] as mgn_norm_update does -- with the
+ * new row count `count` (host scalar, already including `rows`) or, when count_dev is not NULL, with *count_dev += rows
+ * in device memory as mgn_norm_update_counted does.  Same values as the four separate calls, bit for bit. */
+int mgn_node_features_sums(const float* world_pos, const float* mesh_pos, const float* phi, const float* swelling_phi,
+                           int32_t n_swell, const float* node_type, const float* mat_param /*or NULL*/, float* feat,
+                           int64_t n_nodes, void* scratch, void* stream);
+int mgn_edge_features_sums(const float* world_pos, const float* mesh_pos, const float* phi, const int32_t* csr_sender,
+                           const int32_t* csr_recv, float* feat /*[E][7]*/, int64_t n_edges, void* scratch, void* stream);
+int mgn_norm_fold(const void* scratch, int64_t rows, int32_t n_feat, float* acc_sum, float* acc_sumsq,
+                  int64_t* count_dev /*or NULL*/, int64_t count, float eps, float* mean_std /*[2F]*/, void* stream);
+
 /* mgn_feature_sums without a workspace argument and without any allocation: the per-block partial
  * sums go to a 256 KiB buffer inside the library's code object (one copy per GPU, held until the
  * process ends).  No counterpart in the reference; it exists for callers that cannot allocate or
@@ -284,6 +299,13 @@ int mgn_decode(const float* x /*[N][H]*/, const mgn_mlp* dec, int32_t time_dim, 
                float* delta_norm /*[T][N][out_dim] or NULL*/,
                const float* out_mean_std, const float* world_pos, const float* phi, const float* node_type,
                float* pred /*[T][N][3] or NULL*/, int64_t n_nodes, void* stream);
+
+/* mgn_decode in its pred mode plus the state feedback of the rollout loop (core/rollout.py:29-32: the last predicted
+ * step becomes the next step's world_pos / phi): pred[T-1][n] is also written to next_world[n][0..1], next_phi[n].
+ * next_world / next_phi may be world_pos / phi themselves: a row's current state is read before it is overwritten. */
+int mgn_decode_step(const float* x /*[N][H]*/, const mgn_mlp* dec, int32_t time_dim, const float* out_mean_std,
+                    const float* world_pos, const float* phi, const float* node_type, float* pred /*[T][N][3]*/,
+                    float* next_world /*[N][2]*/, float* next_phi /*[N]*/, int64_t n_nodes, void* stream);
 
 /* mgn_decode for the multiscale model, whose decoder reads cat[x, x2] (fine latents | coarse latents mapped back,
  * core/meshgraphnet.py:192-194, :156): dec->w0 is [H][2H].  hidden_ws [N][H] is caller-provided scratch for the

@@ -508,3 +508,72 @@ def test_constant_weights_scope():
     assert not torch.equal(changed, ref)
     with model.constant_weights():
         assert torch.equal(model.predict(g), changed)
+
+
+@pytest.mark.parametrize("nx,ny", [(33, 17), (400, 300)])
+def test_features_with_sums_and_folded_update_equal_the_separate_launches(nx, ny):
+    """Feature rows + per-block column sums in one launch and final sum + statistics update in one more
+    (mgn_node_features_sums / mgn_edge_features_sums / mgn_norm_fold) against the four separate launches
+    (features, mgn_feature_sums, mgn_norm_update): features, accumulators and [mean | std] bit for bit, with the
+    row count on the host and in device memory, one block of partials and many."""
+    from gnn_amd import ops
+    from gnn_amd.graph import Topology
+    g = O.synthetic_graph(nx, ny, seed=6)
+    gg = graph_to(g, DEV)
+    n = g["mesh_pos"].shape[0]
+    topo = Topology(g["edge_index"], n, DEV)
+    e = topo.num_edges
+    world, mesh, phi = gg["world_pos"].float().contiguous(), gg["mesh_pos"].float().contiguous(), gg["phi"].float().contiguous()
+    swell, ntype, mat = gg["swelling_phi"].float().contiguous(), gg["node_type"].float().contiguous(), gg["mat_param"].float().contiguous()
+    for kind in ("node", "edge"):
+        rows, f = (n, 12) if kind == "node" else (e, 7)
+        feat_a, feat_b = torch.empty(rows, f, device=DEV), torch.full((rows, f), float("nan"), device=DEV)
+        part = torch.full((ops.feature_sums_scratch_bytes(rows, f) // 8,), float("nan"), dtype=torch.float64, device=DEV)
+        scratch = torch.empty_like(part)
+        if kind == "node":
+            ops.node_features(world, mesh, phi, swell, ntype, mat, feat_a)
+            ops.node_features(world, mesh, phi, swell, ntype, mat, feat_b, partials=part)
+        else:
+            ops.edge_features(world, mesh, phi, topo.sender, topo.recv, feat_a)
+            ops.edge_features(world, mesh, phi, topo.sender, topo.recv, feat_b, partials=part)
+        assert torch.equal(feat_a, feat_b)
+        gen = torch.Generator().manual_seed(3)
+        acc0, sq0 = torch.rand(1, f, generator=gen).to(DEV) * 100, torch.rand(1, f, generator=gen).to(DEV) * 1000
+        sums = torch.empty(2 * f, dtype=torch.float64, device=DEV)
+        ops.feature_sums(feat_a, sums, scratch)
+        for counted in (False, True):
+            acc_a, sq_a, acc_b, sq_b = acc0.clone(), sq0.clone(), acc0.clone(), sq0.clone()
+            ms_a, ms_b = torch.empty(2 * f, device=DEV), torch.empty(2 * f, device=DEV)
+            if counted:
+                ca, cb = torch.tensor([777], dtype=torch.int64, device=DEV), torch.tensor([777], dtype=torch.int64, device=DEV)
+                ops.norm_update_counted(acc_a, sq_a, sums, ca, rows, 1e-8, ms_a)
+                ops.norm_fold(part, rows, acc_b, sq_b, cb, 0, 1e-8, ms_b)
+                assert int(ca) == int(cb) == 777 + rows
+            else:
+                ops.norm_update(acc_a, sq_a, sums, 777 + rows, 1e-8, ms_a)
+                ops.norm_fold(part, rows, acc_b, sq_b, None, 777 + rows, 1e-8, ms_b)
+            assert torch.equal(acc_a, acc_b) and torch.equal(sq_a, sq_b) and torch.equal(ms_a, ms_b), (kind, counted)
+
+
+def test_mean_std_of_unchanged_statistics_is_not_recomputed_and_never_stale():
+    """``stats_for(None, accumulate=False)`` keeps [mean | std] while nothing changed, and recomputes after an
+    accumulation, after the statistics tensors were replaced (same shape, same count) and after an in-place edit."""
+    from gnn_amd.normalization import Normalizer
+    nrm = Normalizer(1, 3, "t", DEV)
+    x = torch.randn(1, 50, 3, generator=torch.Generator().manual_seed(0)).to(DEV)
+    nrm(x)
+    first = nrm.stats_for(None, accumulate=False).clone()
+    assert nrm.stats_for(None, accumulate=False).data_ptr() == nrm._work()["mean_std"].data_ptr()
+    assert torch.equal(nrm.stats_for(None, accumulate=False), first)
+    nrm(2 * x + 1)
+    second = nrm.stats_for(None, accumulate=False).clone()
+    assert not torch.equal(first, second)
+    nrm._max_accumulations = 0
+    old_sum = nrm._acc_sum
+    nrm._acc_sum = (old_sum * 3).clone()                      # replaced: another tensor, same shape and count
+    del old_sum
+    third = nrm.stats_for(None, accumulate=False).clone()
+    assert not torch.equal(third, second) and abs(float(third[0]) - 3 * float(second[0])) < 1e-5 * abs(float(third[0])) + 1e-7
+    nrm._acc_sum.mul_(0.5)                                    # edited in place
+    fourth = nrm.stats_for(None, accumulate=False)
+    assert abs(float(fourth[0]) - 1.5 * float(second[0])) < 1e-5 * abs(float(fourth[0])) + 1e-7
