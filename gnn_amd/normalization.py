@@ -145,9 +145,10 @@ class Normalizer(nn.Module):
             self._acc_count += added
             self._num_accumulations += 1
             w["fresh"] = None
-        elif w.get("count_dev") is None:
-            # nothing accumulates: [mean | std] of unchanged statistics is still in the buffer (the statistics change
-            # only through the kernels launched here, through replaced tensors or through in-place torch operations)
+        else:
+            # nothing accumulates: [mean | std] of unchanged statistics is still in the buffer.  The statistics change
+            # only through the kernels launched here (each of which rewrites the buffer), through replaced tensors or
+            # through in-place torch operations; with the row count in device memory, host and device counts move together
             key = self._stats_key()
             hit = w.get("fresh")
             if hit is not None and hit[0] == key:

@@ -122,6 +122,9 @@ def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
             from tqdm import tqdm
             steps = tqdm(steps, desc="Rollout")
         captured = None
+        # plain model on one GPU: the decoder launch writes the new state over the old one (no separate copies)
+        in_place = (getattr(model, "__dict__", {}).get("halo") is None and getattr(model, "sample_ratio", 0.0) == 0
+                    and hasattr(model, "constant_weights"))
         if _wants_graph(model, first, use_graph) and n_frames > 2 * time_dim:
             cur["swelling_phi"] = sched[0: time_dim + 1].T.contiguous().to(torch.float32)
             captured = _StepGraph(model, cur)
@@ -132,10 +135,13 @@ def rollout(model, data, progress: bool = False, reorder=None, use_graph=None):
                     preds.append(captured.step().clone())
                     continue
                 cur["swelling_phi"] = sched[t: t + time_dim + 1].T.contiguous()
-                pred = model.predict(cur, check_range=False)       # checked once, after the loop
-                last = pred[-1]
-                cur["world_pos"] = last[:, :2].contiguous()
-                cur["phi"] = last[:, 2:].contiguous()
+                if in_place:
+                    pred = model.predict(cur, check_range=False, feedback=True)       # range checked once, after the loop
+                else:
+                    pred = model.predict(cur, check_range=False)
+                    last = pred[-1]
+                    cur["world_pos"] = last[:, :2].contiguous()
+                    cur["phi"] = last[:, 2:].contiguous()
                 preds.append(pred)
         finally:
             if captured is not None:
