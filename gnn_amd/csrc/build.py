@@ -64,5 +64,20 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def build_examples() -> str:
+    """The C++ host example (no Python, no torch): links against the library through its C ABI alone."""
+    root = os.path.abspath(os.path.join(PKG, ".."))
+    src, out = os.path.join(root, "examples", "partitioned_step.cpp"), os.path.join(root, "examples", "partitioned_step")
+    if os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(src), os.path.getmtime(OUT)):
+        return out
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), src,
+           "-L", PKG, "-lmgn_hip", "-Wl,-rpath,$ORIGIN/../gnn_amd", "-o", out]
+    res = subprocess.run(cmd, cwd=root, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc (example) failed:\n" + res.stdout + res.stderr)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_examples())
