@@ -100,6 +100,8 @@ SIGNATURES = {
     "mgn_halo_stage_state": (C.c_int, [_P, _P, _I64, _P, _I64, _P, _P, _P, _P]),
     "mgn_halo_unpack_state": (C.c_int, [_P, _I64, _P, _P, _P]),
     "mgn_fps": (C.c_int, [_P, _I32, _P, _P, _P, _I32, _I64, _P, _P, _P]),
+    "mgn_fps_workspace_floats": (_I64, [_I64]),
+    "mgn_fps_single": (C.c_int, [_P, _I32, _I64, _I64, _I64, _P, _P, _P]),
     "mgn_knn_graph": (C.c_int, [_P, _I32, _P, _P, _P, _I32, _I64, _I32, _P, _P, _P]),
 }
 

@@ -157,6 +157,96 @@ void dispatch_fps(long long max_block, int n_blocks, hipStream_t s, const float*
     else launch_fps<DIM, 0>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
 }
 
+// ---- one mesh too large for one compute unit to sweep per sample: two launches per sample over the whole GPU.
+// fps_round_kernel: every workgroup updates the running distances of its contiguous slice against the last sample
+// (read from *cur) and leaves its slice's best (distance, index) in part[]; fps_pick_kernel: one workgroup folds the
+// slices' winners (lowest index among equal distances, as above), writes the sample and *cur for the next round.
+// The same values and the same choices as fps_kernel; the launches of a stream run in order, nothing waits in a kernel.
+constexpr int FPSR_T = 256;
+constexpr int FPSR_MAX_G = 1024;
+
+template <int DIM>
+__global__ __launch_bounds__(FPSR_T) void fps_round_kernel(const float* __restrict__ P, int n, const int* __restrict__ cur,
+                                                           float* __restrict__ D, float* __restrict__ part_v,
+                                                           int* __restrict__ part_i, int first_round) {
+    const int tid = threadIdx.x;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int j0 = blockIdx.x * per, j1 = min(n, j0 + per);
+    const int c = *cur;
+    float q[DIM];
+#pragma unroll
+    for (int k = 0; k < DIM; ++k) q[k] = P[(size_t)c * DIM + k];
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int j = j0 + tid; j < j1; j += FPSR_T) {
+        float p[DIM];
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) p[k] = P[(size_t)j * DIM + k];
+        const float d = fps_distance<DIM>(p, q), old = first_round ? __builtin_inff() : D[j];
+        const float nd = d < old ? d : old;
+        if (first_round || d < old) D[j] = nd;
+        if (nd > bv) { bv = nd; bi = j; }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        keep_better(bv, bi, ov, oi);
+    }
+    __shared__ float sv[FPSR_T / 64];
+    __shared__ int si[FPSR_T / 64];
+    if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < FPSR_T / 64; ++w) keep_better(bv, bi, sv[w], si[w]);
+        part_v[blockIdx.x] = bv; part_i[blockIdx.x] = bi;
+    }
+}
+
+__global__ __launch_bounds__(FPSR_T) void fps_pick_kernel(const float* __restrict__ part_v, const int* __restrict__ part_i,
+                                                          int g, int* __restrict__ cur, long long* __restrict__ out_slot,
+                                                          long long base) {
+    const int tid = threadIdx.x;
+    float bv = -1.f;
+    int bi = 0x7fffffff;
+    for (int b = tid; b < g; b += FPSR_T) keep_better(bv, bi, part_v[b], part_i[b]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const float ov = __shfl_xor(bv, o);
+        const int oi = __shfl_xor(bi, o);
+        keep_better(bv, bi, ov, oi);
+    }
+    __shared__ float sv[FPSR_T / 64];
+    __shared__ int si[FPSR_T / 64];
+    if ((tid & 63) == 0) { sv[tid >> 6] = bv; si[tid >> 6] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < FPSR_T / 64; ++w) keep_better(bv, bi, sv[w], si[w]);
+        *cur = bi;
+        *out_slot = base + bi;
+    }
+}
+
+__global__ void fps_first_kernel(int start, int* __restrict__ cur, long long* __restrict__ out_slot, long long base) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { *cur = start; *out_slot = base + start; }
+}
+
+template <int DIM>
+void fps_by_rounds(const float* P, int n, int m, int start, long long base, float* D, float* extra, long long* out, hipStream_t s) {
+    float* part_v = extra;
+    int* part_i = reinterpret_cast<int*>(extra + FPSR_MAX_G);
+    int* cur = reinterpret_cast<int*>(extra + 2 * FPSR_MAX_G);
+    int g = (n + 4 * FPSR_T - 1) / (4 * FPSR_T);
+    g = g > FPSR_MAX_G ? FPSR_MAX_G : (g < 1 ? 1 : g);
+    hipLaunchKernelGGL(fps_first_kernel, dim3(1), dim3(64), 0, s, start, cur, out, base);
+    for (int it = 1; it < m; ++it) {
+        hipLaunchKernelGGL((fps_round_kernel<DIM>), dim3(g), dim3(FPSR_T), 0, s, P, n, (const int*)cur, D, part_v, part_i,
+                           it == 1 ? 1 : 0);
+        hipLaunchKernelGGL(fps_pick_kernel, dim3(1), dim3(FPSR_T), 0, s, (const float*)part_v, (const int*)part_i, g, cur,
+                           out + it, base);
+    }
+}
+
 constexpr int KNN_T = 256;
 
 // One thread per query point; the block's points pass through LDS 256 at a time, in ascending index order, so a
@@ -246,6 +336,22 @@ bool dispatch_knn(int k, dim3 grid, hipStream_t s, const float* pts, const long 
 }
 
 }  // namespace
+
+extern "C" int64_t mgn_fps_workspace_floats(int64_t n_points) {
+    return n_points < 0 ? -1 : n_points + 2 * FPSR_MAX_G + 64;
+}
+
+extern "C" int mgn_fps_single(const float* points, int32_t dim, int64_t n_points, int64_t n_samples, int64_t start,
+                              float* workspace, int64_t* out_idx, void* stream) {
+    const char* name = "mgn_fps_single";
+    MGN_REQUIRE((dim == 2 || dim == 3) && n_points > 0 && n_points < (1ll << 31) - 4096 && n_samples >= 0, name);
+    if (n_samples == 0) return 0;
+    MGN_REQUIRE(points && workspace && out_idx && start >= 0 && start < n_points && n_samples < (1ll << 31), name);
+    hipStream_t s = (hipStream_t)stream;
+    if (dim == 2) fps_by_rounds<2>(points, (int)n_points, (int)n_samples, (int)start, 0, workspace, workspace + n_points, (long long*)out_idx, s);
+    else fps_by_rounds<3>(points, (int)n_points, (int)n_samples, (int)start, 0, workspace, workspace + n_points, (long long*)out_idx, s);
+    return check_launch(name);
+}
 
 extern "C" int mgn_fps(const float* points, int32_t dim, const int32_t* node_ptr, const int32_t* sample_ptr,
                        const int32_t* starts, int32_t n_blocks, int64_t max_block_nodes, float* dist_ws, int64_t* out_idx,

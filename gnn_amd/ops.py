@@ -599,6 +599,7 @@ def halo_unpack_state(recv_buf, n_owned, world_local, phi_local):
 
 # --------------------------------------------------------------------------- device: coarse graph (multiscale option)
 FPS_REGISTER_MAX = 16384          # blocks up to this size need no distance workspace
+FPS_ROUNDS_MIN = 30000            # a single mesh beyond this size is sampled with two launches per sample over the whole GPU
 
 
 def _block_ptr(sizes, device) -> torch.Tensor:
@@ -623,6 +624,12 @@ def fps(points, block_sizes, sample_counts, starts) -> torch.Tensor:
     dev = points.device
     out = torch.empty(sum(counts), dtype=torch.int64, device=dev)
     if not sizes or out.numel() == 0:
+        return out
+    if len(sizes) == 1 and n >= FPS_ROUNDS_MIN and torch.cuda.is_current_stream_capturing() is False:
+        ws = torch.empty(int(_lib.lib().mgn_fps_workspace_floats(n)), dtype=torch.float32, device=dev)
+        rc = _lib.lib().mgn_fps_single(_dev(points, torch.float32, (n, dim), "points"), dim, n, counts[0], int(starts[0]),
+                                       ws.data_ptr(), out.data_ptr(), _stream())
+        _lib.check(rc, "mgn_fps_single")
         return out
     biggest = max(sizes)
     ws = torch.empty(n, dtype=torch.float32, device=dev) if biggest > FPS_REGISTER_MAX else None

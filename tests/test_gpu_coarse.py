@@ -35,6 +35,9 @@ SAMPLING = [
     ("distances in device memory", lambda: _cloud(20000, 2, 4), 150, 12345),
     ("distances in device memory, 3-D grid-like", lambda: torch.cat([_grid(150, 120, 1.0, 1.0), torch.zeros(18000, 1)], 1), 120, 7),
     ("more samples than distinct points", lambda: torch.cat([_cloud(30, 2, 5)] * 2), 45, 1),
+    ("two launches per sample over the whole GPU", lambda: _cloud(40000, 2, 6), 150, 39999),
+    ("two launches per sample, regular grid", lambda: _grid(250, 160, 1.0, 1.0), 130, 0),
+    ("two launches per sample, 3-D", lambda: _cloud(70001, 3, 7), 90, 5),
 ]
 
 
@@ -46,6 +49,23 @@ def test_device_sampling_equals_the_reference_expressions(what, make, m, start):
     got = ops.fps(pts.to(DEV), [n], [m], [start]).cpu()
     want = farthest_point_sampling(pts, m, start)
     assert got.dtype == torch.int64 and torch.equal(got, want), (what, int((got != want).nonzero()[0]))
+
+
+def test_both_sampling_kernels_agree_on_a_large_mesh():
+    """The single-workgroup kernel (what a batch of meshes uses) and the per-sample launch sequence on the same
+    100 000 points: the same samples."""
+    import ctypes as C
+    from gnn_amd import _lib, ops
+    pts = _cloud(100000, 2, 9).to(DEV)
+    n, m = pts.shape[0], 300
+    by_rounds = ops.fps(pts, [n], [m], [77])
+    ws = torch.empty(n, dtype=torch.float32, device=DEV)
+    one_block = torch.empty(m, dtype=torch.int64, device=DEV)
+    ptrs = [torch.tensor(v, dtype=torch.int32, device=DEV) for v in ([0, n], [0, m], [77])]
+    rc = _lib.lib().mgn_fps(pts.data_ptr(), 2, ptrs[0].data_ptr(), ptrs[1].data_ptr(), ptrs[2].data_ptr(), 1, n, ws.data_ptr(),
+                            one_block.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    _lib.check(rc, "mgn_fps")
+    assert torch.equal(by_rounds, one_block)
 
 
 @pytest.mark.parametrize("tag,ratio", [("ms", 0.5), ("both", 0.4)])
