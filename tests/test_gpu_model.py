@@ -577,3 +577,25 @@ def test_mean_std_of_unchanged_statistics_is_not_recomputed_and_never_stale():
     nrm._acc_sum.mul_(0.5)                                    # edited in place
     fourth = nrm.stats_for(None, accumulate=False)
     assert abs(float(fourth[0]) - 1.5 * float(second[0])) < 1e-5 * abs(float(fourth[0])) + 1e-7
+
+
+@pytest.mark.parametrize("time_dim", [1, 2, 3])
+def test_decoder_state_feedback_equals_predict_plus_copies(time_dim):
+    """``predict(feedback=True)`` (mgn_decode_step: the decoder launch writes the last predicted step over the current
+    state) against ``predict`` followed by the two copies of core/rollout.py:29-32: predictions and the new state bit for
+    bit over three steps, also when several predicted steps read the state that the last one overwrites."""
+    cfg = O.OracleConfig(node_in_dim=3 + (time_dim + 1) + 5, process_steps=2, time_dim=time_dim)
+    sd = O.init_state_dict(cfg, 3)
+    g = O.synthetic_graph(29, 14, seed=2, time_dim=time_dim)
+    a, b = build_model(cfg, sd), build_model(cfg, sd)
+    ga, gb = graph_to(g, DEV), graph_to(g, DEV)
+    for k in ("world_pos", "phi"):
+        ga[k], gb[k] = ga[k].float().contiguous().clone(), gb[k].float().contiguous().clone()
+    for _ in range(3):
+        pa = a.predict(ga)
+        ga["world_pos"], ga["phi"] = pa[-1][:, :2].contiguous(), pa[-1][:, 2:].contiguous()
+        pb = b.predict(gb, feedback=True)
+        assert torch.equal(pa, pb)
+        assert torch.equal(ga["world_pos"], gb["world_pos"]) and torch.equal(ga["phi"], gb["phi"])
+    with pytest.raises(RuntimeError):
+        b.predict({**{k: v for k, v in gb.items()}, "world_pos": gb["world_pos"].double()}, feedback=True)
