@@ -625,7 +625,7 @@ def fps(points, block_sizes, sample_counts, starts) -> torch.Tensor:
     out = torch.empty(sum(counts), dtype=torch.int64, device=dev)
     if not sizes or out.numel() == 0:
         return out
-    if len(sizes) == 1 and n >= FPS_ROUNDS_MIN and torch.cuda.is_current_stream_capturing() is False:
+    if len(sizes) == 1 and n >= FPS_ROUNDS_MIN and not torch.cuda.is_current_stream_capturing():
         ws = torch.empty(int(_lib.lib().mgn_fps_workspace_floats(n)), dtype=torch.float32, device=dev)
         rc = _lib.lib().mgn_fps_single(_dev(points, torch.float32, (n, dim), "points"), dim, n, counts[0], int(starts[0]),
                                        ws.data_ptr(), out.data_ptr(), _stream())
@@ -815,8 +815,9 @@ class DeferredReductions:
         need = (need + 255) & ~255
         while self.chunk < 0 or self.offset + need > self.chunks[self.chunk].numel():
             self.chunk, self.offset = self.chunk + 1, 0
-            if self.chunk == len(self.chunks):
-                self.chunks.append(torch.empty(max(need, 256 << 20), dtype=torch.uint8, device=self.device))
+            if self.chunk == len(self.chunks):       # a new chunk: at least twice the last one, so large steps need few
+                size = max(need, 8 << 20, 2 * self.chunks[-1].numel() if self.chunks else 0)
+                self.chunks.append(torch.empty(size, dtype=torch.uint8, device=self.device))
         ptr = self.chunks[self.chunk].data_ptr() + self.offset
         self.offset += need
         return ptr
