@@ -471,9 +471,12 @@ def main():
                                "floor_ms": {"hbm": t_floor_hbm * 1e3, "mfma": t_floor_mfma * 1e3},
                                # the counter traffic (e rows, node-side gathers and sums included) over this launch time,
                                # beside what plain streaming kernels reach on this GPU (scripts/micro/hbm_stream.hip, 3 GiB
-                               # arrays: copy 4.7-5.4, 2 reads + 1 write 4.7-5.3 TB/s)
+                               # arrays: copy 5.0-5.4, 2 reads + 1 write 5.3-5.6 TB/s; profiles/r03_hbm_stream.txt) and the
+                               # time of a kernel that only performs this kernel's memory traffic on the 1M-node mesh
+                               # (scripts/micro/edge_stream.hip, profiles/r03_edge_stream.txt: 8 and 2 workgroups per CU)
                                "moved_GBs": (traffic / t_edge / 1e9) if traffic else None,
-                               "streaming_kernel_GBs_measured": [4700.0, 5400.0]}
+                               "streaming_kernel_GBs_measured": [5000.0, 5600.0],
+                               "traffic_only_kernel_ms_measured_at_1M_nodes": [1.55, 1.69]}
             if "mp_node" in kern_ms:
                 # second kernel of the step: node update + next block's projections, 2560 algorithmic bytes per node
                 # (x and aggr in; x, ps, pr out); the last block writes no projections (averaged like the edge kernel)
