@@ -227,3 +227,67 @@ def test_plan_from_a_rank_local_strip_equals_plan_from_the_global_edge_list():
                 assert torch.equal(gl[k], full[k][ids]), k
     with pytest.raises(ValueError):
         HaloPlan.from_local(ei, np.zeros((2, 0), dtype=np.int64), n_total, e_total, 2, 0)   # receivers of rank 1 among the in-edges
+
+
+def _coarse_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gnn_amd.coarse import sample_and_connect
+        from gnn_amd.partition import CoarsePartition, HaloPlan
+        g = O.synthetic_graph(17, 11, seed=3)
+        n = g["mesh_pos"].shape[0]
+        plan = HaloPlan(g["edge_index"].numpy(), n, world, rank).to("cpu")
+        ids = torch.from_numpy(plan.local_node_ids)
+        mesh_local = g["mesh_pos"].float()[ids]
+        cp = CoarsePartition(plan, mesh_local, 0.4, 5)
+        # the state of the local coarse rows: owned rows taken from the rank's own arrays, halo rows from their owners
+        world_l, phi_l = g["world_pos"].float()[ids].contiguous(), g["phi"].float()[ids].contiguous()
+        cw, cphi = cp.state(world_l, phi_l)
+        first, ei, counts = sample_and_connect(g["mesh_pos"].float(), 0.4, [5])      # the whole coarse graph, one process
+        first_sorted, order = torch.sort(first)
+        mesh_of_local = first_sorted[torch.from_numpy(cp.plan.local_node_ids)]       # mesh node of every local coarse row
+        ret[f"state_{rank}"] = bool(torch.equal(cw, g["world_pos"].float()[mesh_of_local])
+                                    and torch.equal(cphi, g["phi"].float()[mesh_of_local])
+                                    and torch.equal(cp.mesh, g["mesh_pos"].float()[mesh_of_local]))
+        ret[f"first_{rank}"] = bool(torch.equal(cp.first_local + plan.bounds[rank], mesh_of_local[: cp.num_owned]))
+        ret[f"owned_{rank}"] = bool(((mesh_of_local[: cp.num_owned] >= plan.bounds[rank])
+                                     & (mesh_of_local[: cp.num_owned] < plan.bounds[rank + 1])).all())
+        # this rank's coarse edges as (sender mesh node, receiver mesh node), in local order
+        le = torch.from_numpy(cp.plan.local_edge_index)
+        ret[f"edges_{rank}"] = mesh_of_local[le].tolist()
+        ret[f"counts_{rank}"] = (cp.num_global, cp.edges_global, cp.plan.global_nodes, cp.plan.global_edges)
+        if rank == 0:
+            ret["global_edges"] = first[ei].tolist()                                 # the same pairs from the whole graph
+            ret["global_counts"] = (counts[0], int(ei.shape[1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_coarse_graph_of_a_partitioned_mesh_is_the_whole_coarse_graph(world):
+    """gloo, CPU tensors: every rank gathers the mesh coordinates, builds the same coarse graph (host sampling and kNN)
+    and keeps the part whose receivers it owns.  The ranks' parts together are the coarse graph of the whole mesh, every
+    receiver's in-edges in the whole graph's order; owned coarse rows lie in the rank's node range; the per-step
+    state of owned and halo coarse rows is the state of their mesh nodes."""
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_coarse_worker, args=(world, port, ret), nprocs=world, join=True)
+    m, ec = ret["global_counts"]
+    glob = ret["global_edges"]                        # [2][Ec] mesh-node pairs, grouped by receiver, nearest first
+    per_receiver = {}
+    for s, r in zip(glob[0], glob[1]):
+        per_receiver.setdefault(r, []).append(s)
+    seen = 0
+    for rank in range(world):
+        assert ret[f"state_{rank}"] and ret[f"first_{rank}"] and ret[f"owned_{rank}"]
+        assert ret[f"counts_{rank}"] == (m, ec, m, ec)
+        mine = {}
+        snd, rcv = ret[f"edges_{rank}"]
+        for s, r in zip(snd, rcv):
+            mine.setdefault(r, []).append(s)
+        for r, senders in mine.items():
+            assert per_receiver[r] == senders         # same in-edges, same order
+        seen += len(snd)
+    assert seen == ec
