@@ -1105,6 +1105,7 @@ extern "C" int mgn_train_defer_reductions(MgnReduceRec* recs, int32_t capacity, 
 
 extern "C" int mgn_train_reduce_many(const MgnReduceRec* recs, int32_t n, void* stream) {
     MGN_REQUIRE(n >= 0 && (n == 0 || recs), "mgn_train_reduce_many");
+    if (n == 0) return 0;
     for (int i = 0; i < n; ++i) {
         const MgnReduceRec& r = recs[i];
         MGN_REQUIRE(r.partial && r.nblocks > 0 && r.stride > 0 && r.mcount >= 0 && r.nvec >= 0 && r.nvec <= 3, "mgn_train_reduce_many");

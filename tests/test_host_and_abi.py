@@ -183,3 +183,47 @@ def test_size_limits_are_rejected_on_the_host():
     assert lib.mgn_train_attn_edge_bwd(None, None, None, None, None, None, None, None, 0, None) == 0
     assert lib.mgn_train_attn_alpha_bwd(None, None, None, None, 0, None) == 0
     assert lib.mgn_train_attn_node_grad(None, None, None, None, None, None, 0, 0, None) == 0
+
+
+def test_argument_checks_of_the_coarse_graph_feedback_and_reduction_entry_points():
+    """The entry points added for the coarse graph, the folded launches and the deferred reductions refuse bad
+    arguments on the host (nothing is launched, no pointer is followed) and accept empty inputs."""
+    import ctypes as C
+    from gnn_amd import _lib
+    lib = _lib.lib()
+    p = C.c_void_p(0x1000)
+    mlp = _lib.MgnMlp(0x1000, 0x1000, 0x1000, 0x1000, 0, 0)
+    # farthest-point sampling / nearest neighbours
+    assert lib.mgn_fps(p, 4, p, p, p, 1, 10, None, p, None) == -1 and b"mgn_fps" in lib.mgn_last_error()      # dim 4
+    assert lib.mgn_fps(p, 2, p, p, p, 1, 20000, None, p, None) == -1          # beyond the register variants without a workspace
+    assert lib.mgn_fps(p, 2, None, p, p, 1, 10, None, p, None) == -1
+    assert lib.mgn_fps(None, 2, None, None, None, 0, 0, None, None, None) == 0
+    assert lib.mgn_fps_workspace_floats(1000) >= 1000 and lib.mgn_fps_workspace_floats(-1) == -1
+    assert lib.mgn_fps_single(p, 2, 100, 10, 100, p, p, None) == -1           # first sample outside the mesh
+    assert lib.mgn_fps_single(p, 2, 100, 10, 5, None, p, None) == -1          # no workspace
+    assert lib.mgn_fps_single(p, 2, 100, 0, 5, None, None, None) == 0         # nothing to sample
+    assert lib.mgn_knn_graph(p, 2, None, p, p, 1, 10, 5, p, p, None) == -1 and b"k = 5" in lib.mgn_last_error()
+    assert lib.mgn_knn_graph(p, 2, None, p, p, 1, 10, 0, p, p, None) == -1
+    assert lib.mgn_knn_graph(p, 2, None, p, p, 70000, 10, 3, p, p, None) == -1                                  # more blocks than a grid dimension holds
+    assert lib.mgn_knn_graph(None, 2, None, None, None, 0, 0, 3, None, None, None) == 0
+    # features with sums, folded statistics update, decoder with state feedback
+    assert lib.mgn_node_features_sums(p, p, p, p, 2, p, None, p, 10, None, None) == -1                          # no partial-sum space
+    assert lib.mgn_node_features_sums(p, p, p, p, 9, p, None, p, 10, p, None) == -1                             # 17 feature columns
+    assert lib.mgn_edge_features_sums(p, p, p, p, p, p, 1 << 31, p, None) == -1
+    assert lib.mgn_norm_fold(p, 10, 17, p, p, None, 10, 1e-8, p, None) == -1
+    assert lib.mgn_norm_fold(None, 10, 7, p, p, None, 10, 1e-8, p, None) == -1
+    assert lib.mgn_decode_step(p, C.byref(mlp), 11, p, p, p, p, p, p, p, 10, None) == -1                        # 33 outputs
+    assert lib.mgn_decode_step(p, C.byref(mlp), 1, p, p, p, p, p, None, p, 10, None) == -1                      # no next-state buffer
+    assert lib.mgn_decode_step(None, C.byref(mlp), 1, None, None, None, None, None, None, None, 0, None) == 0
+    # deferred reductions: a record list needs room and a counter; records are validated before the launch
+    recs = (_lib.MgnReduceRec * 2)()
+    cnt = C.c_int32(0)
+    assert lib.mgn_train_defer_reductions(recs, 0, C.byref(cnt)) == -1
+    assert lib.mgn_train_defer_reductions(recs, 2, None) == -1
+    cnt.value = 3
+    assert lib.mgn_train_defer_reductions(recs, 2, C.byref(cnt)) == -1                                          # count beyond the capacity
+    cnt.value = 0
+    assert lib.mgn_train_defer_reductions(recs, 2, C.byref(cnt)) == 0 and lib.mgn_train_defer_reductions(None, 0, None) == 0
+    assert lib.mgn_train_reduce_many(recs, 1, None) == -1                                                       # an empty record
+    assert lib.mgn_train_reduce_many(None, 0, None) == 0
+    assert lib.mgn_train_partial_bytes(3, 10) == -1 and lib.mgn_train_partial_bytes(0, -1) == -1
