@@ -1,5 +1,5 @@
 #!/bin/bash
-# Traffic and occupancy counter passes of the processor kernels at 1M nodes for this round's tree (GPU box): one
+# Traffic and occupancy counter passes of the processor kernels at 1M nodes (GPU box): one
 # rocprofv3 --pmc run per pass, per-kernel means into gpurun_out/pmc_r03_<pass>.txt (edge and node kernels both listed).
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
