@@ -22,12 +22,13 @@ def _wants_graph(model, first, use_graph):
     of at most 50 000 edges.  There a step's ~40 launches occupy the GPU for less time (0.35 ms at 561 nodes) than
     the host needs to issue them (0.45 ms), and replaying the captured step takes 0.39 ms; at 200 000 edges the
     host keeps ahead of the GPU and replay is the slower of the two.  Results are bit-identical either way.  Not
-    with a partitioned model, and not with the coarse branch (its graph is redrawn per call)."""
+    with a partitioned model, and with the coarse branch only while its first sample is pinned
+    (``model.coarse_start``: otherwise the coarse graph is redrawn per call)."""
     if use_graph is None:
         env = os.environ.get("MGN_ROLLOUT_GRAPH", "")
         use_graph = first["edge_index"].shape[1] <= GRAPH_AUTO_MAX_EDGES if env == "" else env != "0"
     return (bool(use_graph) and model.__dict__.get("halo") is None and torch.device(model.device).type == "cuda"
-            and getattr(model, "sample_ratio", 0.0) == 0)
+            and (getattr(model, "sample_ratio", 0.0) == 0 or model.__dict__.get("coarse_start") is not None))
 
 
 class _StepGraph:
@@ -41,10 +42,16 @@ class _StepGraph:
 
     def __init__(self, model, cur):
         self.model, self.cur = model, cur
-        self.norms = (model.node_features_normalizer, model.edge_features_normalizer, model.output_normalizer)
+        self.plain = getattr(model, "sample_ratio", 0.0) == 0
+        # the feature normalisers (they accumulate while live), then the output normaliser (read only)
+        feature_norms = (model.node_features_normalizer, model.edge_features_normalizer)
+        if not self.plain:
+            feature_norms += (model.coarse_edge_features_normalizer,)
+        self.n_feature_norms = len(feature_norms)
+        self.norms = feature_norms + (model.output_normalizer,)
         for nr in self.norms:
             nr.use_device_count(True)
-        self.accumulating = [nr._num_accumulations < nr._max_accumulations for nr in self.norms[:2]]
+        self.accumulating = [nr._num_accumulations < nr._max_accumulations for nr in feature_norms]
         state = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -61,8 +68,13 @@ class _StepGraph:
             nr._acc_count, nr._num_accumulations = c, k
 
     def _body(self):
-        # the decoder launch writes the new state over the old one (no separate copies)
-        return self.model.predict(self.cur, check_range=False, feedback=True)
+        if self.plain:                            # the decoder launch writes the new state over the old one
+            return self.model.predict(self.cur, check_range=False, feedback=True)
+        pred = self.model.predict(self.cur, check_range=False)
+        last = pred[-1]
+        self.cur["world_pos"].copy_(last[:, :2])
+        self.cur["phi"].copy_(last[:, 2:])
+        return pred
 
     def _snapshot(self):
         norms = [(nr._acc_sum.clone(), nr._acc_sum_squared.clone(), nr._acc_count, nr._num_accumulations) for nr in self.norms]
@@ -78,11 +90,11 @@ class _StepGraph:
 
     def valid(self) -> bool:
         """The captured sequence accumulates (or not) as it did at capture time."""
-        return self.accumulating == [nr._num_accumulations < nr._max_accumulations for nr in self.norms[:2]]
+        return self.accumulating == [nr._num_accumulations < nr._max_accumulations for nr in self.norms[: self.n_feature_norms]]
 
     def step(self):
         self.graph.replay()
-        for nr, rows, acc in zip(self.norms[:2], self.rows_added[:2], self.accumulating):
+        for nr, rows, acc in zip(self.norms[: self.n_feature_norms], self.rows_added, self.accumulating):
             if acc:
                 nr.count_replayed(rows)
         return self.pred

@@ -514,3 +514,31 @@ def test_attention_gradients_with_the_relu_pattern_pinned(nx, ny, steps):
         worst = max(worst, (k, r), key=lambda t: t[1])
     assert any("attn_lin" in k and float(pinned[k].abs().max()) > 0 for k in sd)
     print("worst gradient rel-L2 with the pattern pinned: %s %.2e" % worst)
+
+
+def test_graph_replayed_rollout_with_a_pinned_coarse_graph_equals_eager():
+    """The multiscale model replays its rollout step from a captured graph while the first sample of its coarse graph
+    is pinned (the graph is then built once): predictions bit-identical to the eager loop, all four normalisers --
+    the coarse-edge one included -- in the same state at the end; with the first sample drawn per call the rollout
+    stays eager."""
+    import gnn_amd
+    from gnn_amd.rollout import _wants_graph, rollout
+    cfg = O.OracleConfig(process_steps=2, attention=True, sample_ratio=0.4, coarse_process_steps=2)
+    sd = O.init_state_dict(cfg, 5)
+    frames = gnn_amd.synthetic_frames(14, 9, n_frames=12, seed=3)
+    outs = []
+    for use_graph in (False, True):
+        model = build(cfg, sd)
+        model.coarse_start = 9
+        assert _wants_graph(model, frames[0], True)
+        res = rollout(model, frames, use_graph=use_graph)
+        outs.append((res["pred"], [(nr._acc_sum.clone(), nr._acc_sum_squared.clone(), nr._acc_count, nr._num_accumulations)
+                                   for _, nr in norm_pairs(model, cfg)]))
+        assert all(nr._work().get("count_dev") is None for _, nr in norm_pairs(model, cfg))
+    (pa, na), (pb, nb) = outs
+    assert torch.equal(pa, pb)
+    for (s1, q1, c1, k1), (s2, q2, c2, k2) in zip(na, nb):
+        assert torch.equal(s1, s2) and torch.equal(q1, q2) and c1 == c2 and k1 == k2
+    assert na[3][3] == 12                                            # the coarse-edge statistics accumulated every step
+    model.coarse_start = None
+    assert not _wants_graph(model, frames[0], True)
