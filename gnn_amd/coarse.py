@@ -96,10 +96,18 @@ class CoarseGraph:
         n_coarse = sum(counts)
         self.num_nodes, self.block_sizes = n_coarse, counts
         self.first = first.to(device)                                      # int64, for row gather / scatter
-        self.topology = Topology(self.edge_index.to(device) if first.is_cuda else self.edge_index, n_coarse, device)
-        first32 = self.first.to(torch.int32)
-        self.sender_orig = first32[self.topology.sender.long()].contiguous()
-        self.recv_orig = first32[self.topology.recv.long()].contiguous()
+        # both builders emit the edges grouped by point, points ascending: that is receiver-major order already, with
+        # min(k, block size - 1) in-edges per point
+        k = 4 if mesh_pos.shape[-1] == 3 else 3
+        degree = np.concatenate([np.full(m, min(k, m - 1), dtype=np.int64) for m in counts]) if counts else np.zeros(0, np.int64)
+        rowptr = np.zeros(n_coarse + 1, dtype=np.int64)
+        np.cumsum(degree, out=rowptr[1:])
+        if rowptr[-1] != self.edge_index.shape[1]:
+            raise RuntimeError("coarse graph: the nearest-neighbour graph has an unexpected number of edges")
+        self.topology = Topology.from_receiver_major(self.edge_index, torch.from_numpy(rowptr.astype(np.int32)), n_coarse, device,
+                                                     int(degree.max()) if degree.size else 0)
+        orig = self.first.to(torch.int32)[self.edge_index.to(device)]         # mesh node ids of both end points, [2, Ec]
+        self.sender_orig, self.recv_orig = orig[0].contiguous(), orig[1].contiguous()
 
     @property
     def first_cpu(self) -> torch.Tensor:

@@ -17,8 +17,7 @@
 
 namespace {
 
-constexpr int FPS_T = 1024;                 // one workgroup of 16 waves per block of the batch
-constexpr int FPS_W = FPS_T / 64;
+constexpr int FPS_T = 1024;                 // one workgroup of 16 waves per block of the batch (4 waves for blocks of up to 1024 points)
 constexpr int FPS_MAX_R = 16;               // up to 16 points per thread are kept in registers
 
 __device__ inline void keep_better(float& bv, int& bi, float v, int i) {
@@ -40,8 +39,8 @@ __device__ inline float fps_distance(const float* p, const float* q) {
 // R > 0: block sizes up to R * FPS_T, points and running distances in registers.  R == 0: any size, running distances
 // in `dist` (one float per point of the batch), points re-read every round (they stay in L2 up to a few hundred
 // thousand points).  One barrier per sample: the wave winners go through two alternating LDS slots.
-template <int DIM, int R>
-__global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pts, const int* __restrict__ node_ptr,
+template <int DIM, int R, int T>
+__global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ pts, const int* __restrict__ node_ptr,
                                                      const int* __restrict__ samp_ptr, const int* __restrict__ starts,
                                                      float* __restrict__ dist, long long* __restrict__ out) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -50,16 +49,16 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
     if (m <= 0) return;
     int cur = starts[b];
     if (n <= 0 || cur < 0 || cur >= n) {            // nothing to sample from, or a first sample outside the block
-        for (int i = tid; i < m; i += FPS_T) out[m0 + i] = -1;
+        for (int i = tid; i < m; i += T) out[m0 + i] = -1;
         return;
     }
     const float* P = pts + (size_t)n0 * DIM;
     float* D = dist + n0;
-    __shared__ __align__(16) float s_v[2][FPS_W];
-    __shared__ __align__(16) int s_i[2][FPS_W];
+    __shared__ __align__(16) float s_v[2][(T / 64)];
+    __shared__ __align__(16) int s_i[2][(T / 64)];
     // blocks of up to 4096 points also sit in LDS: the winner's coordinates are then an LDS read away instead of a
     // dependent round trip to L2 (the larger part of a round on a mesh of a few hundred nodes)
-    constexpr int LDS_PTS = (R > 0 && R <= 4) ? R * FPS_T : 1;
+    constexpr int LDS_PTS = (R > 0 && R <= 4) ? R * T : 1;
     __shared__ float s_p[LDS_PTS * DIM];
     constexpr int RR = R > 0 ? R : 1;
     float pr[RR][DIM], dr[RR];
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
     if (R > 0) {
 #pragma unroll
         for (int r = 0; r < RR; ++r) {
-            const int j = tid + r * FPS_T;
+            const int j = tid + r * T;
             dr[r] = j < n ? inf : -1.f;              // a slot without a point never wins (distances are >= 0)
 #pragma unroll
             for (int k = 0; k < DIM; ++k) pr[r][k] = j < n ? P[(size_t)j * DIM + k] : 0.f;
@@ -78,7 +77,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
         }
         if (LDS_PTS > 1) __syncthreads();
     } else {
-        for (int j = tid; j < n; j += FPS_T) D[j] = inf;
+        for (int j = tid; j < n; j += T) D[j] = inf;
     }
     if (tid == 0) out[m0] = (long long)n0 + cur;
     for (int it = 1; it < m; ++it) {
@@ -93,22 +92,22 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
                 const float d = fps_distance<DIM>(pr[r], q);
                 const float nd = dr[r] < 0.f ? -1.f : (d < dr[r] ? d : dr[r]);
                 dr[r] = nd;
-                if (nd > bv) { bv = nd; bi = tid + r * FPS_T; }      // ascending ids per thread: the first maximum stays
+                if (nd > bv) { bv = nd; bi = tid + r * T; }      // ascending ids per thread: the first maximum stays
             }
         } else {
             constexpr int U = 8;                       // loads of eight points in flight per thread
-            for (int j0 = tid; j0 < n; j0 += U * FPS_T) {
+            for (int j0 = tid; j0 < n; j0 += U * T) {
                 float p[U][DIM], old[U];
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int j = j0 + u * FPS_T;
+                    const int j = j0 + u * T;
                     old[u] = j < n ? D[j] : -1.f;
 #pragma unroll
                     for (int k = 0; k < DIM; ++k) p[u][k] = j < n ? P[(size_t)j * DIM + k] : 0.f;
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
-                    const int j = j0 + u * FPS_T;
+                    const int j = j0 + u * T;
                     const float d = fps_distance<DIM>(p[u], q);
                     const float nd = d < old[u] ? d : old[u];
                     if (j < n && d < old[u]) D[j] = d;
@@ -131,7 +130,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
         const int4* si4 = reinterpret_cast<const int4*>(s_i[slot]);
         bv = -1.f; bi = 0x7fffffff;
 #pragma unroll
-        for (int w = 0; w < FPS_W / 4; ++w) {
+        for (int w = 0; w < (T / 64) / 4; ++w) {
             const float4 v = sv4[w];
             const int4 i = si4[w];
             keep_better(bv, bi, v.x, i.x); keep_better(bv, bi, v.y, i.y);
@@ -142,19 +141,20 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ pt
     }
 }
 
-template <int DIM, int R>
+template <int DIM, int R, int T>
 void launch_fps(int n_blocks, hipStream_t s, const float* pts, const int* node_ptr, const int* samp_ptr, const int* starts,
                 float* dist, long long* out) {
-    hipLaunchKernelGGL((fps_kernel<DIM, R>), dim3(n_blocks), dim3(FPS_T), 0, s, pts, node_ptr, samp_ptr, starts, dist, out);
+    hipLaunchKernelGGL((fps_kernel<DIM, R, T>), dim3(n_blocks), dim3(T), 0, s, pts, node_ptr, samp_ptr, starts, dist, out);
 }
 
 template <int DIM>
 void dispatch_fps(long long max_block, int n_blocks, hipStream_t s, const float* pts, const int* node_ptr,
                   const int* samp_ptr, const int* starts, float* dist, long long* out) {
-    if (max_block <= 1 * FPS_T) launch_fps<DIM, 1>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
-    else if (max_block <= 4 * FPS_T) launch_fps<DIM, 4>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
-    else if (max_block <= FPS_MAX_R * FPS_T) launch_fps<DIM, FPS_MAX_R>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
-    else launch_fps<DIM, 0>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
+    // meshes of a few hundred nodes: four waves (a cheap barrier, one wave per SIMD), four points per thread
+    if (max_block <= 4 * 256) launch_fps<DIM, 4, 256>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
+    else if (max_block <= 4 * FPS_T) launch_fps<DIM, 4, FPS_T>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
+    else if (max_block <= FPS_MAX_R * FPS_T) launch_fps<DIM, FPS_MAX_R, FPS_T>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
+    else launch_fps<DIM, 0, FPS_T>(n_blocks, s, pts, node_ptr, samp_ptr, starts, dist, out);
 }
 
 // ---- one mesh too large for one compute unit to sweep per sample: two launches per sample over the whole GPU.

@@ -133,6 +133,20 @@ class Topology:
         self._sender_view = None
         self._min_deg = {}
 
+    @classmethod
+    def from_receiver_major(cls, edge_index: torch.Tensor, rowptr: torch.Tensor, num_nodes: int, device, max_in_degree: int):
+        """For an edge list that already is in receiver-major order (receivers ascending; ``rowptr`` int32 [N+1] given):
+        no sort, no round trip to the host.  The k-nearest-neighbour graph of the coarse branch comes out this way."""
+        t = cls.__new__(cls)
+        t.num_nodes, t.num_edges, t.device = int(num_nodes), int(edge_index.shape[1]), torch.device(device)
+        t.rowptr = rowptr.to(t.device, torch.int32).contiguous()
+        t.sender = edge_index[0].to(t.device, torch.int32).contiguous()
+        t.recv = edge_index[1].to(t.device, torch.int32).contiguous()
+        t.perm = torch.arange(t.num_edges, dtype=torch.int64, device=t.device)
+        t.max_in_degree = int(max_in_degree)
+        t._sender_view, t._min_deg = None, {}
+        return t
+
     def min_in_degree(self, first_rows: int = None) -> int:
         """Smallest in-degree among the first ``first_rows`` nodes (default: all), looked up once per topology."""
         n = self.num_nodes if first_rows is None else int(first_rows)

@@ -491,7 +491,7 @@ int mgn_halo_unpack_state(const float* recv_buf, int64_t n_halo, float* world_ha
  *   draws it with torch.randint, :248), each further one torch.argmax of the running minimum of
  *   torch.norm(points - last, dim=-1): float32, fused multiply-add chain over the coordinates, rounded square root,
  *   lowest index among equal distances -- the choices of the reference's expressions on the CPU.  A block whose start
- *   lies outside [0, block size) gets -1 in all its slots.  One 1024-thread workgroup per block; blocks of up to
+ *   lies outside [0, block size) gets -1 in all its slots.  One workgroup per block (four waves up to 1024 points, sixteen beyond); blocks of up to
  *   16 384 points keep everything in registers, larger ones keep the running distances in dist_ws (one float per
  *   point of the batch, may be NULL if max_block_nodes <= 16 384).  dim is 2 or 3; coordinates must be finite.
  *   Cost: (number of samples) rounds over the block's points on one compute unit.
