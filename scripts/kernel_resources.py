@@ -9,7 +9,7 @@ import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gnn_amd", "csrc")
 rows = []
-for f in ("mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip"):
+for f in ("mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip", "mgn_halo.hip", "mgn_coarse.hip"):
     res = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Rpass-analysis=kernel-resource-usage",
                           "-o", os.devnull, os.path.join(SRC, f)], cwd=SRC, capture_output=True, text=True)
     cur = None
