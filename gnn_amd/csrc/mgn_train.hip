@@ -294,42 +294,121 @@ __global__ __launch_bounds__(NT, 2) void train_linear_bwd_kernel(LinBwdArgs a) {
 // ------------------------------------------------------------------------ linear backward, split-bf16 path
 // Same contract as train_linear_bwd_kernel with both products on the bf16 matrix pipe (three exact
 // bf16 terms per fp32 operand, six partial products; gradients keep their full exponent range).
-//   GA = G W      : contraction over the Linear's outputs f; G tile as row-major planes, W^T in registers.
-//   dW = G^T A    : contraction over the 32 rows of the tile; both tiles as TRANSPOSED planes
-//                   (feature-major, 8 consecutive rows = one 16-byte operand fragment).
-// One workgroup per CU (the LDS images of a tile take 104 KB); the next tile's rows are loaded into
-// registers while the current tile's products run.
-constexpr int TK = TM + 8;                  // halves per feature row of a transposed plane (64 B + 16 B pad)
-constexpr int TPLANE = H * TK;              // halves per transposed plane
+//   GA = G W      : contraction over the Linear's outputs f; operand = 8 consecutive features of one tile row
+//                   (one 16-byte row read), W^T in registers.
+//   dW = G^T A    : contraction over the 32 rows of the tile; operand = 8 consecutive rows of one feature,
+//                   fetched from the SAME row-major image with the transposing LDS read (ds_read_b64_tr_b16:
+//                   per 16 lanes a block of 4 rows x 16 columns, lane i receives column i), two reads per operand.
+// One image per plane serves both: 256-byte rows without padding, the 16-byte chunk ch of row r stored at chunk
+// ch ^ (4 (r & 3) | ((r >> 2) & 3)), which keeps the row reads, the transposed reads and the 8-byte stores
+// free of bank conflicts (scripts/micro/tr_read.hip checks the lane map and the swizzle on the device).
+// One workgroup per CU (weight planes and gradient accumulators take 160 registers per lane); the next tile's rows
+// are requested as soon as the current tile's have been staged.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
 
-// halves offset of rows 8*blk .. 8*blk+7 of feature f; the four 16-byte blocks of a feature row are
-// permuted by bits 4-5 of f so that the transposing stores of a wave spread over the LDS banks
-__device__ __forceinline__ int tpos(int f, int blk) { return f * TK + 8 * (blk ^ ((f >> 4) & 3)); }
+constexpr int SPL = TM * H;                 // halves per plane of the image
 
-// rows r0, r0+1 (r0 even) x features k..k+3: transposed planes, and optionally the row-major planes
-template <bool ROWMAJOR, bool TRANSPOSED>
-__device__ __forceinline__ void stage_rows2(unsigned short* rm, unsigned short* tp, int r0, int k, const f32x4 v0, const f32x4 v1) {
-    unsigned h0[4], m0[4], l0[4], h1[4], m1[4], l1[4];
+__device__ __forceinline__ int swz_off(int row, int ch) { return row * H + 8 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// four consecutive features k .. k+3 (k a multiple of 4) of one tile row -> the three planes
+__device__ __forceinline__ void splanes_store4(unsigned short* img, int row, int k, const f32x4 v) {
+    u32x2 ph, pm, pl;
+    split_pack4(v, ph, pm, pl);
+    unsigned short* d = img + swz_off(row, k >> 3) + (k & 4);
+    *(u32x2*)(d) = ph; *(u32x2*)(d + SPL) = pm; *(u32x2*)(d + 2 * SPL) = pl;
+}
+
+// The transposing read needs every lane of the wave active: call from workgroup-uniform control flow only.
+__device__ __forceinline__ u32x2 lds_tr4(const unsigned short* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p));
+}
+
+// halves offset of this lane's address for the block of rows 16s + 8h + 4hh + 0..3, columns 32 blk + 16 gg + 0..15
+// (h = lane >> 5, gg = bit 4 of the lane): lane 4q + p of the 16 supplies row q, columns 4p .. 4p+3
+__device__ __forceinline__ int tr_off(int lane, int s, int hh, int blk) {
+    const int h = lane >> 5, gg = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    return swz_off(16 * s + 8 * h + 4 * hh + q, 4 * blk + 2 * gg + (p >> 1)) + 4 * (p & 1);
+}
+
+// The addresses of the other column blocks and of the second 16 rows follow from the one of block 0, rows 0..15:
+// the block index only enters bits 5-6 of the halves offset (through the swizzle: an XOR), s adds 16 rows.
+struct TrBase { int o[2]; };                 // hh = 0, 1
+__device__ __forceinline__ TrBase tr_base(int lane) { return TrBase{{tr_off(lane, 0, 0, 0), tr_off(lane, 0, 1, 0)}}; }
+
+// v_mfma_f32_32x32x16_bf16 operand of lane (j = lane & 31, h = lane >> 5): rows 16s + 8h + 0..7 of column 32 blk + j
+__device__ __forceinline__ void tr_operand3(const unsigned short* img, const TrBase& tb, int s, int blk, u32x4& xh, u32x4& xm, u32x4& xl) {
+    const unsigned short* p0 = img + ((tb.o[0] ^ (32 * blk)) + 16 * H * s);
+    const unsigned short* p1 = img + ((tb.o[1] ^ (32 * blk)) + 16 * H * s);
+    const u32x2 h0 = lds_tr4(p0), h1 = lds_tr4(p1), m0 = lds_tr4(p0 + SPL), m1 = lds_tr4(p1 + SPL);
+    const u32x2 l0 = lds_tr4(p0 + 2 * SPL), l1 = lds_tr4(p1 + 2 * SPL);
+    xh = u32x4{h0[0], h0[1], h1[0], h1[1]};
+    xm = u32x4{m0[0], m0[1], m1[0], m1[1]};
+    xl = u32x4{l0[0], l0[1], l1[0], l1[1]};
+}
+
+// wave_gemm3_32 on the swizzled image.  rb = swz_off(j, h), the lane's offset for k-step 0; k-step c sits at rb ^ 16c
+// (2c + h = 2c ^ h, and the swizzle is an XOR as well), so one register carries all eight addresses.
+template <int C0, int C1>
+__device__ __forceinline__ f32x16 wave_gemm3_32s(const unsigned short* img, const WPlanes32& w, int rb, f32x16 acc) {
+    const unsigned short* r = img + (rb ^ (16 * C0));
+    u32x4 xh = *(const u32x4*)(r), xm = *(const u32x4*)(r + SPL), xl = *(const u32x4*)(r + 2 * SPL);
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { split3(v0[c], h0[c], m0[c], l0[c]); split3(v1[c], h1[c], m1[c], l1[c]); }
-    if constexpr (ROWMAJOR) {
-        unsigned short* d0 = rm + r0 * PK + k;
-        unsigned short* d1 = d0 + PK;
-        *(u32x2*)(d0) = u32x2{pack_hi16(h0[0], h0[1]), pack_hi16(h0[2], h0[3])};
-        *(u32x2*)(d0 + PLANE) = u32x2{pack_hi16(m0[0], m0[1]), pack_hi16(m0[2], m0[3])};
-        *(u32x2*)(d0 + 2 * PLANE) = u32x2{pack_hi16(l0[0], l0[1]), pack_hi16(l0[2], l0[3])};
-        *(u32x2*)(d1) = u32x2{pack_hi16(h1[0], h1[1]), pack_hi16(h1[2], h1[3])};
-        *(u32x2*)(d1 + PLANE) = u32x2{pack_hi16(m1[0], m1[1]), pack_hi16(m1[2], m1[3])};
-        *(u32x2*)(d1 + 2 * PLANE) = u32x2{pack_hi16(l1[0], l1[1]), pack_hi16(l1[2], l1[3])};
-    }
-    if constexpr (TRANSPOSED) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            unsigned* d = (unsigned*)(tp + tpos(k + c, r0 >> 3) + (r0 & 7));
-            d[0] = pack_hi16(h0[c], h1[c]);
-            d[TPLANE / 2] = pack_hi16(m0[c], m1[c]);
-            d[TPLANE] = pack_hi16(l0[c], l1[c]);
+    for (int c = C0; c < C1; ++c) {
+        u32x4 nh = xh, nm = xm, nl = xl;
+        if (c + 1 < C1) {
+            const unsigned short* n = img + (rb ^ (16 * (c + 1)));
+            nh = *(const u32x4*)(n); nm = *(const u32x4*)(n + SPL); nl = *(const u32x4*)(n + 2 * SPL);
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
         }
+        acc = mfma32_bf16(w.p[2][c], xh, acc);   // lo * hi
+        acc = mfma32_bf16(w.p[0][c], xl, acc);   // hi * lo
+        acc = mfma32_bf16(w.p[1][c], xm, acc);   // mid * mid
+        acc = mfma32_bf16(w.p[1][c], xh, acc);   // mid * hi
+        acc = mfma32_bf16(w.p[0][c], xm, acc);   // hi * mid
+        acc = mfma32_bf16(w.p[0][c], xh, acc);   // hi * hi
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        xh = nh; xm = nm; xl = nl;
+    }
+    return acc;
+}
+
+// Accumulator layout -> image: lane (j, h) of wave w holds features 32w + 8g + 4h + 0..3 of row j in registers
+// 4g .. 4g+3.  sb = swz_off(j, 4w) + 4h is the offset of group 0; group g sits at sb ^ 8g.
+__device__ __forceinline__ void splanes_store_acc4(unsigned short* img, int sb, int g, const f32x4 v) {
+    u32x2 ph, pm, pl;
+    split_pack4(v, ph, pm, pl);
+    unsigned short* d = img + (sb ^ (8 * g));
+    *(u32x2*)(d) = ph; *(u32x2*)(d + SPL) = pm; *(u32x2*)(d + 2 * SPL) = pl;
+}
+
+__device__ __forceinline__ int opaque(int x) {       // the value as the optimiser cannot see through: what is derived from
+    asm volatile("" : "+v"(x));                       // it is formed where it is used, not kept in registers across a tile
+    return x;
+}
+
+// dw[kb] += G^T A over the 32 rows of the tile: feature block `w` of G (this wave's 32 weight rows) against the column
+// blocks kb = KB0 .. KB0+NKB-1 of A.  Partial products smallest first, per accumulator in the order of wave_gemm3_32.
+template <int KB0, int NKB>
+__device__ __forceinline__ void wave_outer3(const unsigned short* Gimg, const unsigned short* Aimg, const TrBase& tb, int w, f32x16* dw) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        u32x4 gh, gm, gl, ah[NKB], am[NKB], al[NKB];
+        tr_operand3(Gimg, tb, s, w, gh, gm, gl);
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) tr_operand3(Aimg, tb, s, KB0 + q, ah[q], am[q], al[q]);
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) dw[KB0 + q] = mfma32_bf16(gl, ah[q], dw[KB0 + q]);
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) dw[KB0 + q] = mfma32_bf16(gh, al[q], dw[KB0 + q]);
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) dw[KB0 + q] = mfma32_bf16(gm, am[q], dw[KB0 + q]);
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) dw[KB0 + q] = mfma32_bf16(gm, ah[q], dw[KB0 + q]);
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) dw[KB0 + q] = mfma32_bf16(gh, am[q], dw[KB0 + q]);
+#pragma unroll
+        for (int q = 0; q < NKB; ++q) dw[KB0 + q] = mfma32_bf16(gh, ah[q], dw[KB0 + q]);
     }
 }
 
@@ -348,11 +427,12 @@ __device__ __forceinline__ void load_wplanes32_t(WPlanes32& w, const float* __re
     }
 }
 
+struct TileRows { f32x4 g[4], a[4], m[4], r[4]; };     // one thread's share of a tile: rows srow + 8*it, columns 4*sq ..
+
 template <bool DO_GA, bool DO_DW>
 __global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned short Gp[DO_GA ? 3 * PLANE : 8];      // G tile, row-major planes
-    __shared__ __attribute__((aligned(16))) unsigned short GT[DO_DW ? 3 * TPLANE : 8];     // G tile, transposed planes
-    __shared__ __attribute__((aligned(16))) unsigned short AT[DO_DW ? 3 * TPLANE : 8];     // A tile, transposed planes
+    __shared__ __attribute__((aligned(16))) unsigned short Gs[3 * SPL];                    // G tile, three planes
+    __shared__ __attribute__((aligned(16))) unsigned short As[DO_DW ? 3 * SPL : 8];        // A tile, three planes
     __shared__ __attribute__((aligned(16))) float Ot[tile_floats(H / 4)];                  // GA tile; bias sums at the end
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6, j = lane & 31, h = lane >> 5;
@@ -364,91 +444,68 @@ __global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) 
     f32x4 dbacc = {0.f, 0.f, 0.f, 0.f};
     int t0, t1;
     tile_range(a.rows, t0, t1);
-    const int srow = t >> 5, sq = t & 31;             // this thread stages rows 2*srow + 16*it + {0, 1}, columns 4*sq..
+    const int srow = t >> 5, sq = t & 31;
+    const TrBase tb = tr_base(lane);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4 pg[4], pa[4], pm[4], pr[4];
-    auto prefetch = [&](int tile) {
-        const long long base = (long long)tile * TM;
+    // An absent mask / residual is read all the same, every lane at offset 0 of G (a line that stays in the cache), and
+    // dropped by a select: the tile loop has no branch around a load.
+    const bool has_mask = DO_GA && a.mask, has_res = DO_GA && a.res;
+    const float* mask_p = has_mask ? a.mask : a.G;
+    const float* res_p = has_res ? a.res : a.G;
+    const size_t mmul = has_mask ? 1 : 0, rmul = has_res ? 1 : 0;
+    auto request = [&](TileRows& p, int tile) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long n = min(base + 2 * srow + 16 * (i >> 1) + (i & 1), a.rows - 1);
-            const size_t o = (size_t)n * H + 4 * sq;
-            pg[i] = *(const f32x4*)(a.G + o);
-            if constexpr (DO_DW) pa[i] = *(const f32x4*)(a.A + o);
-            if constexpr (DO_GA) {
-                if (a.mask) pm[i] = *(const f32x4*)(a.mask + o);
-                if (a.res) pr[i] = *(const f32x4*)(a.res + o);
-            }
+        for (int it = 0; it < 4; ++it) {
+            const size_t o = (size_t)min((long long)tile * TM + srow + 8 * it, a.rows - 1) * H + 4 * sq;
+            p.g[it] = *(const f32x4*)(a.G + o);
+            if constexpr (DO_DW) p.a[it] = *(const f32x4*)(a.A + o);
+            if constexpr (DO_GA) { p.m[it] = *(const f32x4*)(mask_p + o * mmul); p.r[it] = *(const f32x4*)(res_p + o * rmul); }
         }
     };
-    if (t0 < t1) prefetch(t0);
-    for (int tile = t0; tile < t1; ++tile) {
+    // One tile: `cur` holds its rows; the next tile's are requested into `nxt` before anything else, so they have the
+    // whole pass to arrive.  The two register sets swap roles from pass to pass (the loop below is unrolled by two):
+    // nothing is copied from one to the other, and no pass ends waiting for its own requests or stores.
+    auto pass = [&](TileRows& cur, TileRows& nxt, int tile) {
         const long long base = (long long)tile * TM;
         const int nvalid = (int)min((long long)TM, a.rows - base);
-        f32x4 cm[4], cr[4];
-        __syncthreads();                           // the previous tile's products and output pass are done
+        request(nxt, min(tile + 1, t1 - 1));         // the last pass requests its own rows again (never used)
+        __syncthreads();                             // the previous tile's products and output pass are done
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int r0 = 2 * srow + 16 * it;
-            const f32x4 g0 = r0 < nvalid ? pg[2 * it] : zero4;          // rows past the end add nothing to the sums
-            const f32x4 g1 = r0 + 1 < nvalid ? pg[2 * it + 1] : zero4;
-            dbacc += g0 + g1;
-            stage_rows2<DO_GA, DO_DW>(Gp, GT, r0, 4 * sq, g0, g1);
-            if constexpr (DO_DW) stage_rows2<false, true>(nullptr, AT, r0, 4 * sq, pa[2 * it], pa[2 * it + 1]);
-        }
-        if constexpr (DO_GA) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { cm[i] = pm[i]; cr[i] = pr[i]; }
+        for (int it = 0; it < 4; ++it) {
+            const f32x4 g = srow + 8 * it < nvalid ? cur.g[it] : zero4;     // rows past the end add nothing to the sums
+            dbacc += g;
+            splanes_store4(Gs, srow + 8 * it, 4 * sq, g);
+            if constexpr (DO_DW) splanes_store4(As, srow + 8 * it, 4 * sq, cur.a[it]);
         }
         __syncthreads();
-        if (tile + 1 < t1) prefetch(tile + 1);
         if constexpr (DO_GA) {
             f32x16 acc = zero16();
-            acc = wave_gemm3_32<0, 8>(Gp, wt, j, h, acc);
+            acc = wave_gemm3_32s<0, 8>(Gs, wt, swz_off(j, h), acc);
             acc_to_tile(Ot, acc, w, j, h);
         }
-        if constexpr (DO_DW) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int blk = 2 * s + h;
-                const unsigned short* gp = GT + tpos(32 * w + j, blk);
-                const u32x4 gh = *(const u32x4*)gp, gm = *(const u32x4*)(gp + TPLANE), gl = *(const u32x4*)(gp + 2 * TPLANE);
-                u32x4 ah[4], am[4], al[4];
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) {
-                    const unsigned short* ap = AT + tpos(32 * kb + j, blk);
-                    ah[kb] = *(const u32x4*)ap; am[kb] = *(const u32x4*)(ap + TPLANE); al[kb] = *(const u32x4*)(ap + 2 * TPLANE);
-                }
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gl, ah[kb], dw[kb]);    // smallest terms first
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gh, al[kb], dw[kb]);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gm, am[kb], dw[kb]);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gm, ah[kb], dw[kb]);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gh, am[kb], dw[kb]);
-#pragma unroll
-                for (int kb = 0; kb < 4; ++kb) dw[kb] = mfma32_bf16(gh, ah[kb], dw[kb]);
-            }
-        }
+        if constexpr (DO_DW) wave_outer3<0, 4>(Gs, As, tb, w, dw);
         if constexpr (DO_GA) {
             __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = 2 * srow + 16 * (i >> 1) + (i & 1);
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
                 if (row < nvalid) {
                     f32x4 val = *(const f32x4*)(Ot + toff(row, sq, H / 4));
-                    if (a.mask) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) val[k] = cm[i][k] > 0.f ? val[k] : 0.f;
+                    for (int k = 0; k < 4; ++k) {
+                        val[k] = (!has_mask || cur.m[it][k] > 0.f) ? val[k] : 0.f;
+                        val[k] += has_res ? cur.r[it][k] : 0.f;
                     }
-                    if (a.res) val += cr[i];
                     *(f32x4*)(a.GA + (size_t)(base + row) * H + 4 * sq) = val;
                 }
             }
         }
+    };
+    TileRows ra, rb;
+    if (t0 < t1) request(ra, t0);
+    for (int tile = t0; tile < t1; tile += 2) {
+        pass(ra, rb, tile);
+        if (tile + 1 < t1) pass(rb, ra, tile + 1);
     }
     if constexpr (DO_DW) {
         float* p = a.partial + (size_t)blockIdx.x * PARTIAL;
@@ -476,9 +533,9 @@ __global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) 
 // hidden activations are recomputed per 32-edge tile with exactly the arithmetic of mp_edge_h4_kernel
 // (same split, same products, same order), so their ReLU patterns are the forward's.  Per tile:
 //   1  h1 = ReLU(ps[s] + pr[r] + W0e e)        fp16-split product; kept in registers (mask), written as
-//                                               fp16 planes (product 2) and transposed bf16 planes (dW2)
+//                                               fp16 planes (product 2) and bf16 planes (dW2, read transposed)
 //   2  v = ReLU(W2 h1 + b2), LayerNorm statistics;  gy = ge + gaggr[r];  LayerNorm backward -> g2
-//      (two row reductions through LDS); g2 as row-major and transposed bf16 planes
+//      (two row reductions through LDS); g2 as bf16 planes, one image for the row reads and the transposed reads
 //   3  dW2 += g2^T h1;  g1 = (g2 W2) * (h1 > 0)   split-bf16 products
 //   4  g1 -> global (coalesced), dpr[r] = sum of g1 over the in-edges of r (same scan as the forward)
 // db2, dgamma, dbeta accumulate per lane in accumulator layout and are reduced once at the end.
@@ -494,38 +551,11 @@ constexpr int PARTIAL_E = H * H + 3 * H;     // dW2 | db2 | dgamma | dbeta
 constexpr int PKH = H + 8;                   // halves per row of an fp16 plane
 constexpr int PLH = TM * PKH;                // halves per fp16 plane
 
-__device__ __forceinline__ float swap_lane1(float x) {       // value of lane ^ 1
-    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xB1, 0xF, 0xF, true));
-}
-
-// accumulator layout (row j = lane & 31; register 4g+k holds feature 32w + 8g + 4h + k) -> transposed bf16
-// planes.  Lanes j and j^1 hold neighbouring rows of the same features: they swap values so that each
-// writes whole dwords (two rows of one feature), eight features per lane.
-__device__ __forceinline__ void tstore_acc(unsigned short* tp, const f32x16& v, int w, int j, int h) {
-    const bool odd = j & 1;
-    const int r0 = j & ~1;
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-        const float o0 = swap_lane1(v[2 * p]), o1 = swap_lane1(v[2 * p + 1]);
-        const float mine = odd ? v[2 * p + 1] : v[2 * p], other = odd ? o1 : o0;
-        unsigned ha, ma, la, hb, mb, lb;
-        split3(odd ? other : mine, ha, ma, la);      // row r0
-        split3(odd ? mine : other, hb, mb, lb);      // row r0 + 1
-        const int g = p >> 1, k = 2 * (p & 1) + (odd ? 1 : 0);
-        const int f = 32 * w + 8 * g + 4 * h + k;
-        unsigned* d = (unsigned*)(tp + tpos(f, r0 >> 3) + (r0 & 7));
-        d[0] = pack_hi16(ha, hb);
-        d[TPLANE / 2] = pack_hi16(ma, mb);
-        d[TPLANE] = pack_hi16(la, lb);
-    }
-}
-
 __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short elP[2 * PLH];        // e tile, fp16 planes
     __shared__ __attribute__((aligned(16))) unsigned short h1P[2 * PLH];        // h1 tile, fp16 planes; then Ot
-    __shared__ __attribute__((aligned(16))) unsigned short H1T[3 * TPLANE];     // h1 tile, transposed bf16 planes
-    __shared__ __attribute__((aligned(16))) unsigned short G2P[3 * PLANE];      // g2 tile, row-major bf16 planes
-    __shared__ __attribute__((aligned(16))) unsigned short G2T[3 * TPLANE];     // g2 tile, transposed bf16 planes
+    __shared__ __attribute__((aligned(16))) unsigned short H1S[3 * SPL];        // h1 tile, bf16 planes (transposed reads)
+    __shared__ __attribute__((aligned(16))) unsigned short G2S[3 * SPL];        // g2 tile, bf16 planes (row and transposed reads)
     __shared__ __attribute__((aligned(16))) float vec[2][H];                    // W_SCALE * b2, gamma
     __shared__ __attribute__((aligned(16))) float red[LN_RED_FLOATS];
     __shared__ __attribute__((aligned(16))) float red2[LN_RED_FLOATS];
@@ -563,6 +593,15 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) pre[it] = *(const f32x4*)(el_g + (unsigned)(min(srow + 8 * it, last) * H + 4 * sq));
     int s_cur = snd_g[min(j, last)], r_cur = rcv_g[min(j, last)];
+    // an absent edge-latent gradient is read all the same (row 0 of e, a line that stays in the cache) and dropped by a select
+    const float* ge_p = ge_g ? ge_g : el_g;
+    const unsigned ge_mul = ge_g ? 1u : 0u;
+    f32x4 gs[4], gr[4];
+    {
+        const unsigned so = (unsigned)s_cur * H + 32 * w + 4 * h, ro = (unsigned)r_cur * H + 32 * w + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gs[g] = *(const f32x4*)(a.ps + so + 8 * g); gr[g] = *(const f32x4*)(a.pr + ro + 8 * g); }
+    }
 #pragma unroll
     for (int it = 0; it < 4; ++it) hplanes_store4(elP, PLH, PKH, srow + 8 * it, 4 * sq, pre[it]);
     __syncthreads();
@@ -571,12 +610,9 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         STAMP(0);
         const int nvalid = min(TM, last + 1 - rel);
         const bool valid = j < nvalid;
-        // requests
-        f32x4 gs[4], gr[4], ye[4], ya[4];
-        const unsigned so = (unsigned)s_cur * H + 32 * w + 4 * h, ro = (unsigned)r_cur * H + 32 * w + 4 * h;
-        const unsigned eo = (unsigned)min(rel + j, last) * H + 32 * w + 4 * h;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { gs[g] = *(const f32x4*)(a.ps + so + 8 * g); gr[g] = *(const f32x4*)(a.pr + ro + 8 * g); }
+        // requests: the next tile of e and of the indices (the gathered projections of this tile were requested during
+        // the previous one)
+        f32x4 ye[4], ya[4];
 #pragma unroll
         for (int it = 0; it < 4; ++it)
             pre[it] = *(const f32x4*)(el_g + (unsigned)(min(rel + TM + srow + 8 * it, last) * H + 4 * sq));
@@ -591,25 +627,25 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         STAMP(2);
         unsigned hmask = 0;                          // bit i: h1 of accumulator register i is positive
         {
-            f32x16 h1;
+            const int sb = swz_off(opaque(j), 4 * w) + 4 * h;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     v[k] = fmaxf(fmaf(acc[4 * g + k], W_UNSCALE, gs[g][k] + gr[g][k]), 0.f);
-                    h1[4 * g + k] = v[k];
                     hmask |= v[k] > 0.f ? 1u << (4 * g + k) : 0u;
                 }
                 hplanes_store4(h1P, PLH, PKH, j, 32 * w + 8 * g + 4 * h, v);
+                splanes_store_acc4(H1S, sb, g, v);
             }
-            tstore_acc(H1T, h1, w, j, h);
         }
         // upstream gradient rows (accumulator layout), consumed after the second product
+        {
+            const unsigned ro = (unsigned)r_cur * H + 32 * w + 4 * h;
+            const unsigned eo = (unsigned)min(rel + j, last) * H * ge_mul + 32 * w + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            ya[g] = *(const f32x4*)(a.gaggr + ro + 8 * g);
-            ye[g] = ge_g ? *(const f32x4*)(ge_g + eo + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int g = 0; g < 4; ++g) { ya[g] = *(const f32x4*)(a.gaggr + ro + 8 * g); ye[g] = *(const f32x4*)(ge_p + eo + 8 * g); }
         }
         STAMP(3);
         __syncthreads();                                                     // (B) h1 planes complete; elP dead
@@ -648,7 +684,7 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int i = 4 * g + k;
-                const float gy = valid ? ye[g][k] + ya[g][k] : 0.f;          // rows past the end add nothing
+                const float gy = valid ? (ge_g ? ye[g][k] : 0.f) + ya[g][k] : 0.f;   // rows past the end add nothing
                 dbet[i] += gy;
                 dgam[i] = fmaf(gy, xh[i], dgam[i]);
                 const float ghv = gy * ga[k];
@@ -659,6 +695,13 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         }
         red2[j * LN_RED_LD + 2 * w + h] = s1;
         red2[j * LN_RED_LD + 8 + 2 * w + h] = s2;
+        // the next tile's projections, into registers the upstream gradient rows have just left: most of a tile to arrive
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const unsigned so = (unsigned)s_nxt * H + 32 * w + 4 * h, ro = (unsigned)r_nxt * H + 32 * w + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { gs[g] = *(const f32x4*)(a.ps + so + 8 * g); gr[g] = *(const f32x4*)(a.pr + ro + 8 * g); }
+        }
         STAMP(7);
         __syncthreads();                                                     // (C2) row sums exchanged
         STAMP(8);
@@ -675,44 +718,24 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
                 db2[i] += g2[i];
             }
         }
+        {
+            const int sb = swz_off(opaque(j), 4 * w) + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            planes_store4(G2P, j, 32 * w + 8 * g + 4 * h, f32x4{g2[4 * g], g2[4 * g + 1], g2[4 * g + 2], g2[4 * g + 3]});
-        tstore_acc(G2T, g2, w, j, h);
+            for (int g = 0; g < 4; ++g)
+                splanes_store_acc4(G2S, sb, g, f32x4{g2[4 * g], g2[4 * g + 1], g2[4 * g + 2], g2[4 * g + 3]});
+        }
         STAMP(9);
         __syncthreads();                                                     // (D) g2 planes complete
         STAMP(10);
         // ---- 3: dW2 += g2^T h1,  g1 = (g2 W2) * (h1 > 0)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int blk = 2 * s + h;
-            const unsigned short* gp = G2T + tpos(32 * w + j, blk);
-            const u32x4 gh = *(const u32x4*)gp, gm = *(const u32x4*)(gp + TPLANE), gl = *(const u32x4*)(gp + 2 * TPLANE);
-#pragma unroll
-            for (int kp = 0; kp < 2; ++kp) {             // two column blocks at a time: 24 operand registers, not 48
-                u32x4 ah[2], am[2], al[2];
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const unsigned short* ap = H1T + tpos(32 * (2 * kp + q) + j, blk);
-                    ah[q] = *(const u32x4*)ap; am[q] = *(const u32x4*)(ap + TPLANE); al[q] = *(const u32x4*)(ap + 2 * TPLANE);
-                }
-#pragma unroll
-                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gl, ah[q], dw2[2 * kp + q]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, al[q], dw2[2 * kp + q]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gm, am[q], dw2[2 * kp + q]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gm, ah[q], dw2[2 * kp + q]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, am[q], dw2[2 * kp + q]);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) dw2[2 * kp + q] = mfma32_bf16(gh, ah[q], dw2[2 * kp + q]);
-            }
+        {
+            const TrBase tb = tr_base(opaque(lane));
+            wave_outer3<0, 2>(G2S, H1S, tb, w, dw2);     // two column blocks at a time: 24 operand registers, not 48
+            wave_outer3<2, 2>(G2S, H1S, tb, w, dw2);
         }
         STAMP(11);
         acc = zero16();
-        acc = wave_gemm3_32<0, 8>(G2P, w2t, j, h, acc);
+        acc = wave_gemm3_32s<0, 8>(G2S, w2t, swz_off(opaque(j), h), acc);
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = (hmask >> i) & 1u ? acc[i] : 0.f;
         acc_to_tile(Ot, acc, w, j, h);

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): cycle shares between the STAMP() points of the fused edge backward kernel.
-Builds a -DMGN_PHASE_STAMPS copy of the library into gpurun_out/ and runs the kernel once.
-    python scripts/edge_bwd_stamps.py [side]"""
+``--build`` (build box) compiles a -DMGN_PHASE_STAMPS copy of the library to scripts/micro/libmgn_stamps.so; without it
+(GPU box) the kernel runs from that copy.
+    python scripts/edge_bwd_stamps.py --build;  python scripts/edge_bwd_stamps.py [side]"""
 import ctypes as C
 import os
 import subprocess
@@ -11,18 +12,22 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "gpurun_out", "libmgn_stamps.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
+out = os.path.join(ROOT, "scripts", "micro", "libmgn_stamps.so")
 src = os.path.join(ROOT, "gnn_amd", "csrc")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMGN_PHASE_STAMPS",
-                       "-o", out, os.path.join(src, "mgn_kernels.hip"), os.path.join(src, "mgn_train.hip"), os.path.join(src, "mgn_graph.hip"), os.path.join(src, "mgn_host.cpp")])
+if "--build" in sys.argv:          # on the build box: the stamped copy travels with the tree
+    sys.path.insert(0, src)
+    from build import SOURCES
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMGN_PHASE_STAMPS",
+                           "-o", out] + [os.path.join(src, f) for f in SOURCES], stderr=subprocess.DEVNULL)
+    sys.exit(0)
 from gnn_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = out
 import gnn_amd  # noqa: E402
 from gnn_amd import ops  # noqa: E402
 
-side = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+side = int(args[0]) if args else 500
 g = gnn_amd.synthetic_frames(side - 1, side - 1)[0]
 dev = "cuda:0"
 n, e = g["mesh_pos"].shape[0], g["edge_index"].shape[1]
@@ -46,9 +51,9 @@ for it in range(3):
     lib.mgn_debug_read_train_stamps(buf, 1)
 print("kernel + reductions: %.3f ms" % t0.elapsed_time(t1))
 vals = list(buf)
-names = {0: "barrier F -> top", 1: "requests", 2: "product 1", 3: "h1: ReLU, fp16 planes, transposed planes", 4: "barrier B",
+names = {0: "barrier F -> top", 1: "requests", 2: "product 1", 3: "h1: ReLU, fp16 planes, bf16 planes", 4: "barrier B",
          5: "product 2, LN statistics, stage next e tile", 6: "barrier C", 7: "LN: xhat, upstream gradient, row sums", 8: "barrier C2",
-         9: "g2, row-major + transposed planes", 10: "barrier D", 11: "dW2 products", 12: "g1 product, mask, -> Ot", 13: "barrier E",
+         9: "g2 -> bf16 planes", 10: "barrier D", 11: "dW2 products", 12: "g1 product, mask, -> Ot", 13: "barrier E",
          14: "scan, row reads", 15: "g1 and dpr stores"}
 ntiles = (e + 31) // 32
 for wsel, label in ((0, "wave 0"), (1, "wave 2")):
