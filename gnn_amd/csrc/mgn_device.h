@@ -459,6 +459,15 @@ __device__ unsigned long long g_stamps[2][16];
 #define STAMP_FLUSH(slot)
 #endif
 
+// The value as the optimiser cannot see through.  Two uses: what is derived from it is formed where it is used instead
+// of being carried in registers across a tile; and a loaded value passed through it has arrived -- placed before a loop,
+// it keeps the wait for a prologue load out of the loop header, where it would also wait for the previous pass's
+// stores (loads and stores share one counter).
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // Blocks b and b + 8 share an XCD (and its L2); hand each XCD a contiguous run of ranges.
 __device__ __forceinline__ int range_of_block(int b, int nb) {
     return (nb & 7) ? b : (b & 7) * (nb >> 3) + (b >> 3);

@@ -811,6 +811,11 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
         STAMP(9);
         __syncthreads();                                             // (4) new x complete
         STAMP(10);
+        // The next tile's rows (requested after barrier 1) are taken as arrived here, before this tile's first store:
+        // loads and stores share one counter that only counts down in order, so a wait for these rows placed after
+        // the stores (where the compiler would put it: at their first use, in the next pass) also waits for the stores.
+#pragma unroll
+        for (int it = 0; it < 4; ++it) asm volatile("" : "+v"(px[it]), "+v"(pa[it]));
         if constexpr (PROJ) {
             // the new rows leave before the projections: their stores queue up behind the matrix instructions
 #pragma unroll

@@ -382,11 +382,6 @@ __device__ __forceinline__ void splanes_store_acc4(unsigned short* img, int sb, 
     *(u32x2*)(d) = ph; *(u32x2*)(d + SPL) = pm; *(u32x2*)(d + 2 * SPL) = pl;
 }
 
-__device__ __forceinline__ int opaque(int x) {       // the value as the optimiser cannot see through: what is derived from
-    asm volatile("" : "+v"(x));                       // it is formed where it is used, not kept in registers across a tile
-    return x;
-}
-
 // dw[kb] += G^T A over the 32 rows of the tile: feature block `w` of G (this wave's 32 weight rows) against the column
 // blocks kb = KB0 .. KB0+NKB-1 of A.  Partial products smallest first, per accumulator in the order of wave_gemm3_32.
 template <int KB0, int NKB>
@@ -486,6 +481,14 @@ __global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) 
         if constexpr (DO_DW) wave_outer3<0, 4>(Gs, As, tb, w, dw);
         if constexpr (DO_GA) {
             __syncthreads();
+            // the next tile's rows are taken as arrived before this tile's stores: loads and stores share one in-order
+            // counter, so a wait for them placed after the stores (at their first use, in the next pass) would
+            // wait for the stores as well
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                asm volatile("" : "+v"(nxt.g[it]), "+v"(nxt.m[it]), "+v"(nxt.r[it]));
+                if constexpr (DO_DW) asm volatile("" : "+v"(nxt.a[it]));
+            }
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int row = srow + 8 * it;
@@ -743,6 +746,10 @@ __global__ __launch_bounds__(NT, 1) void train_edge_bwd_kernel(EdgeBwdArgs a) {
         __syncthreads();                                                     // (E) g1 tile complete
         STAMP(13);
         // ---- 4: g1 rows to memory, receiver-segmented sums
+        // (the next tile's projections are taken as arrived before the stores below: one in-order counter for loads and
+        // stores, so a wait for them placed after the stores would wait for the stores as well)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(gs[g]), "+v"(gr[g]));
         const unsigned mask = (unsigned)__ballot(valid && ra != rb);         // bit r: row r ends its segment
         const unsigned gmask = (mask >> (16 * sg)) & 0xFFFFu;
         float xr[16], part = 0.f;
