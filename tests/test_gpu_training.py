@@ -82,6 +82,37 @@ def test_training_blocks_vs_torch():
     assert float(o1[5].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 65, 32 * 256 * 3 + 17, 32 * 256 * 4 - 5])
+def test_linear_backward_row_counts(rows, matmul_mode):
+    """Linear backward against fp64 torch for row counts around the 32-row tile and for counts that give a workgroup
+    several tiles, odd and even many (the tile loop runs two passes per round over two register sets): input gradient
+    alone, weight gradient alone, both, with and without the ReLU mask and the residual."""
+    from gnn_amd import ops
+    gen = torch.Generator().manual_seed(rows)
+    A, G, M, R = (torch.randn(rows, 128, generator=gen) for _ in range(4))
+    W = torch.randn(128, 256, generator=gen) / 16
+    d = lambda t: t.to(DEV)
+    scratch = torch.empty(ops.train_scratch_bytes(), dtype=torch.uint8, device=DEV)
+    G64, A64, W64 = G.double(), A.double(), W.double()
+    ga_plain, dw_ref, db_ref = G64 @ W64[:, 128:], G64.T @ A64, G64.sum(0)
+    ga_full = ga_plain * (M > 0) + R.double()
+    tol = 5e-6
+    GA, dW, db = torch.empty(rows, 128, device=DEV), torch.zeros(128, 256, device=DEV), torch.empty(128, device=DEV)
+    ops.train_linear_bwd(d(G), scratch, a=d(A), w=d(W), koff=128, mask=d(M), res=d(R), ga=GA, dw=dW, dw_koff=128, db=db)
+    assert rel_l2(GA.double(), ga_full) < tol and rel_l2(dW[:, 128:].double(), dw_ref) < tol and rel_l2(db.double(), db_ref) < tol
+    assert float(dW[:, :128].abs().max()) == 0.0
+    GA2 = torch.empty_like(GA)
+    ops.train_linear_bwd(d(G), scratch, w=d(W), koff=128, ga=GA2)                      # input gradient alone, no mask / residual
+    assert rel_l2(GA2.double(), ga_plain) < tol
+    ops.train_linear_bwd(d(G), scratch, w=d(W), koff=128, res=d(R), ga=GA2)            # residual alone
+    assert rel_l2(GA2.double(), ga_plain + R.double()) < tol
+    dW2, db2 = torch.zeros(128, 256, device=DEV), torch.empty(128, device=DEV)
+    ops.train_linear_bwd(d(G), scratch, a=d(A), dw=dW2, dw_koff=0, db=db2)             # weight gradient alone
+    assert rel_l2(dW2[:, :128].double(), dw_ref) < tol and rel_l2(db2.double(), db_ref) < tol
+    if matmul_mode != "f32":                                                            # one kernel: same bits either way
+        assert torch.equal(dW2[:, :128], dW[:, 128:])
+
+
 class FixedStats(O.NormStats):
     """Normaliser with the mean / std of `src` held as given (no accumulation), in `dtype`."""
 
