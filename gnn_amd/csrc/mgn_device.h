@@ -345,6 +345,43 @@ __device__ __forceinline__ void wave_gemm_h2(const unsigned short* tile, int pla
     }
 }
 
+// wave_gemm_h2 with a piece of unrelated vector / LDS-store work per k-step (`side(c)`, in program order after the
+// step's matrix instructions): with one wave per SIMD the vector ALU has nothing to do while the matrix pipe works
+// through a k-step (six instructions, 32 cycles each), so work placed here costs its issue slots only.
+// NV, NW: vector-ALU instructions and LDS stores of one piece (upper bounds; they size the scheduling groups).
+template <int C0, int C1, int KS, int NV, int NW, typename Side>
+__device__ __forceinline__ void wave_gemm_h2_with(const unsigned short* tile, int plane, int ld, int kbase,
+                                                  const WPlanesH<KS>& wa, const WPlanesH<KS>& wb, int j, int h,
+                                                  f32x16& acc_a, f32x16& acc_b, Side&& side) {
+    const unsigned short* r = tile + j * ld + kbase + 8 * h;
+    u32x4 x1 = *(const u32x4*)(r + 16 * C0), x2 = *(const u32x4*)(r + plane + 16 * C0);
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int c = C0; c < C1; ++c) {
+        u32x4 n1 = x1, n2 = x2;
+        if (c + 1 < C1) {
+            n1 = *(const u32x4*)(r + 16 * (c + 1)); n2 = *(const u32x4*)(r + plane + 16 * (c + 1));
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        acc_a = mfma32_f16(wa.p[1][c], x1, acc_a); acc_b = mfma32_f16(wb.p[1][c], x1, acc_b);   // h2 * h1
+        side(c);
+        acc_a = mfma32_f16(wa.p[0][c], x2, acc_a); acc_b = mfma32_f16(wb.p[0][c], x2, acc_b);   // h1 * h2
+        acc_a = mfma32_f16(wa.p[0][c], x1, acc_a); acc_b = mfma32_f16(wb.p[0][c], x1, acc_b);   // h1 * h1
+        // the step's side work spread between its matrix instructions (left alone, the scheduler piles it up at the end)
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, NV / 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x200, NW, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        x1 = n1; x2 = n2;
+    }
+}
+
 // ======================================================================== split-bf16 matrix path
 // fp32 products on the bf16 matrix pipe.  Every fp32 operand is cut EXACTLY into three bf16
 // terms by truncation (8 + 8 + 8 significant bits: x = hi + mid + lo, no rounding anywhere),

@@ -765,24 +765,28 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
             hplanes_store4(tile, PL, PKH, j, 32 * w + 8 * g + 4 * h, f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]}, m);
         range_report(m);
     };
-    __syncthreads();
+    // piece c (of 8) of staging the rows held in px / pa: x rows in fp32 (residual) and as fp16 planes, aggr rows as planes
+    auto stage_piece = [&](int c, float& m) {
+        const int it = c >> 1, row = srow + 8 * it;
+        if ((c & 1) == 0) {
+            *(f32x4*)(Xf + toff(row, sq, H / 4)) = px[it];
+            hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it], m);
+        } else {
+            hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it], m);
+        }
+    };
+    {
+        float m = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) stage_piece(c, m);
+        range_report(m);
+    }
+    __syncthreads();                                                 // first tile staged
     STAMP_DECL
     for (int tile = t0; tile < t1; ++tile) {
         const int base = tile * TM, nvalid = min(TM, a.n_nodes - base);
-        STAMP(0);
-        {
-            float m = 0.f;
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int row = srow + 8 * it;
-                *(f32x4*)(Xf + toff(row, sq, H / 4)) = px[it];
-                hplanes_store4(XAp, PL2, PKH2, row, 4 * sq, px[it], m);
-                hplanes_store4(XAp, PL2, PKH2, row, H + 4 * sq, pa[it], m);
-            }
-            range_report(m);
-        }
-        STAMP(1);
-        __syncthreads();                                             // (1) tile staged
+        // The tile is staged already (by the previous pass, under its projections): its rows have left px / pa,
+        // which take the next tile's rows now -- most of a pass to arrive.
         STAMP(2);
         prefetch(min(tile + 1, t1 - 1));
         STAMP(3);
@@ -823,32 +827,43 @@ __global__ __launch_bounds__(NT, 1) void mp_node_h_kernel(NodeArgs a) {
                 const int row = srow + 8 * it;
                 if (row < nvalid) *(f32x4*)(a.x_out + (size_t)(base + row) * H + 4 * sq) = *(const f32x4*)(Os + toff(row, sq, H / 4));
             }
+            // The next tile is staged between the matrix instructions of the projections, one piece per k-step: every
+            // wave has passed barrier 4, so nobody reads XAp (product 1) or Xf (residual) of this tile any more.
             f32x16 as = zero16(), ar = zero16();
-            wave_gemm_h2<0, 8, 8>(Np, PL, PKH, 0, ws, wr, j, h, as, ar);
+            float m = 0.f;
+            wave_gemm_h2_with<0, 8, 8, 24, 3>(Np, PL, PKH, 0, ws, wr, j, h, as, ar, [&](int c) { stage_piece(c, m); });
+            range_report(m);
 #pragma unroll
             for (int i = 0; i < 16; ++i) as[i] *= W_UNSCALE;
             ar = finish(ar, vec[4], false);
             acc_to_tile(Ps, as, w, j, h);
             acc_to_tile(Pr, ar, w, j, h);
             STAMP(11);
-            __syncthreads();                                         // (5) projections complete
+            __syncthreads();                                         // (5) projections complete, next tile staged
             STAMP(12);
-        }
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = srow + 8 * it;
-            if (row < nvalid) {
-                const size_t o = (size_t)(base + row) * H + 4 * sq;
-                if constexpr (!PROJ) *(f32x4*)(a.x_out + o) = *(const f32x4*)(Os + toff(row, sq, H / 4));
-                if constexpr (PROJ) {
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
+                if (row < nvalid) {
+                    const size_t o = (size_t)(base + row) * H + 4 * sq;
                     *(f32x4*)(a.ps + o) = *(const f32x4*)(Ps + toff(row, sq, H / 4));
                     *(f32x4*)(a.pr + o) = *(const f32x4*)(Pr + toff(row, sq, H / 4));
                 }
             }
+        } else {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = srow + 8 * it;
+                if (row < nvalid) *(f32x4*)(a.x_out + (size_t)(base + row) * H + 4 * sq) = *(const f32x4*)(Os + toff(row, sq, H / 4));
+            }
+            float m = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) stage_piece(c, m);
+            range_report(m);
+            __syncthreads();                                         // (5) next tile staged
         }
         STAMP(13);
-        // Xf / XAp are rewritten at the top of the next pass, after every thread's last read of them
-        // (before barrier 4 resp. 2); Os / Ps / Pr are rewritten only after the next pass's barriers
+        // Os / Ps / Pr / Hp / Np are rewritten only after the next pass's barriers
     }
     if constexpr (PROJ) { STAMP_FLUSH(w == 0 ? 0 : (w == 2 ? 1 : -1)) }
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic (GPU box): cycle shares between the STAMP() points of the fp16-split node kernel's
-main loop (projections on).  Builds a -DMGN_PHASE_STAMPS copy of the library into gpurun_out/ and runs one layer.
+main loop (projections on).  Uses the -DMGN_PHASE_STAMPS copy of the library that ``python scripts/edge_bwd_stamps.py --build`` leaves in scripts/micro/.
     python scripts/phase_stamps_node.py [side]"""
 import ctypes as C
 import os
@@ -11,11 +11,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-out = os.path.join(ROOT, "gpurun_out", "libmgn_stamps.so")
-os.makedirs(os.path.dirname(out), exist_ok=True)
-src = os.path.join(ROOT, "gnn_amd", "csrc")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMGN_PHASE_STAMPS",
-                       "-o", out, os.path.join(src, "mgn_kernels.hip"), os.path.join(src, "mgn_train.hip"), os.path.join(src, "mgn_graph.hip"), os.path.join(src, "mgn_host.cpp")])
+out = os.path.join(ROOT, "scripts", "micro", "libmgn_stamps.so")      # built by scripts/edge_bwd_stamps.py --build
 from gnn_amd import _lib  # noqa: E402
 
 _lib.LIB_PATH = out
