@@ -19,9 +19,9 @@ for which in base tree base tree; do
     python3 - "$which" "$job" "$f" <<'PY' >> gpurun_out/lib_ab_kernels.txt
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[3])))
-keep = ("train_linear_bwd3_kernel<true, true>", "train_edge_bwd", "mp_edge_h4", "mp_node_h_kernel<true, true>", "train_linear_fwd_kernel<false, true>", "segment_sum")
+keep = ("train_linear_bwd3_kernel<true, true>", "train_edge_bwd", "mp_edge_h4", "mp_node_h_kernel<true, true>", "train_linear_fwd_kernel<false, true>", "segment_sum", "encode_kernel<2", "encode_kernel<3", "decode_kernel", "mp_project")
 out = []
-for r in rows[:8]:
+for r in rows[:12]:
     for k in keep:
         if k in r["Name"]:
             out.append("%s %d x %.1f us" % (k.split("<")[0].replace("_kernel", ""), int(r["Calls"]), float(r["AverageNs"]) / 1e3))
