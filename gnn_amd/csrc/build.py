@@ -9,6 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 SOURCES = ["mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip", "mgn_halo.hip", "mgn_coarse.hip", "mgn_host.cpp"]
 OUT = os.path.join(PKG, "libmgn_hip.so")
+# Per-file compiler flags (none at present).
+EXTRA_FLAGS = {}
 
 
 def hipcc_path() -> str:
@@ -27,7 +29,7 @@ def needs_build() -> bool:
 
 
 def _compile(src: str, obj: str, verbose: bool) -> None:
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     res = subprocess.run(cmd, cwd=HERE, capture_output=True, text=True)

@@ -8,10 +8,14 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gnn_amd", "csrc")
+import sys  # noqa: E402
+sys.path.insert(0, SRC)
+from build import EXTRA_FLAGS  # noqa: E402  (the per-file flags of the product build)
 rows = []
 for f in ("mgn_kernels.hip", "mgn_train.hip", "mgn_graph.hip", "mgn_halo.hip", "mgn_coarse.hip"):
-    res = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Rpass-analysis=kernel-resource-usage",
-                          "-o", os.devnull, os.path.join(SRC, f)], cwd=SRC, capture_output=True, text=True)
+    res = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17"] + EXTRA_FLAGS.get(f, []) +
+                         ["-c", "-Rpass-analysis=kernel-resource-usage", "-o", os.devnull, os.path.join(SRC, f)],
+                         cwd=SRC, capture_output=True, text=True)
     cur = None
     for line in res.stderr.splitlines():
         m = re.search(r"remark: (?:\s*)([A-Za-z ]+(?:\[[^\]]*\])?[A-Za-z ]*): (.*?) \[-Rpass", line)
