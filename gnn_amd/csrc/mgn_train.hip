@@ -444,10 +444,11 @@ __global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // An absent mask / residual is read all the same, every lane at offset 0 of G (a line that stays in the cache), and
     // dropped by a select: the tile loop has no branch around a load.
-    const bool has_mask = DO_GA && a.mask, has_res = DO_GA && a.res;
-    const float* mask_p = has_mask ? a.mask : a.G;
+    // A mask that is the layer input itself (the usual case: the ReLU output that fed this Linear) is not read twice.
+    const bool has_mask = DO_GA && a.mask, has_res = DO_GA && a.res, mask_is_a = DO_GA && DO_DW && a.mask == a.A;
+    const float* mask_p = (has_mask && !mask_is_a) ? a.mask : a.G;
     const float* res_p = has_res ? a.res : a.G;
-    const size_t mmul = has_mask ? 1 : 0, rmul = has_res ? 1 : 0;
+    const size_t mmul = (has_mask && !mask_is_a) ? 1 : 0, rmul = has_res ? 1 : 0;
     auto request = [&](TileRows& p, int tile) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
@@ -496,7 +497,8 @@ __global__ __launch_bounds__(NT, 1) void train_linear_bwd3_kernel(LinBwdArgs a) 
                     f32x4 val = *(const f32x4*)(Ot + toff(row, sq, H / 4));
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        val[k] = (!has_mask || cur.m[it][k] > 0.f) ? val[k] : 0.f;
+                        const float mk = (DO_DW && mask_is_a) ? cur.a[it][k] : cur.m[it][k];
+                        val[k] = (!has_mask || mk > 0.f) ? val[k] : 0.f;
                         val[k] += has_res ? cur.r[it][k] : 0.f;
                     }
                     *(f32x4*)(a.GA + (size_t)(base + row) * H + 4 * sq) = val;
